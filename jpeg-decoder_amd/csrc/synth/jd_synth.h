@@ -1,0 +1,28 @@
+/* jd_synth.h -- synthetic image generator + baseline JPEG encoder (bench/test workload maker). */
+#ifndef JD_SYNTH_H
+#define JD_SYNTH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct jds_image jds_image;
+/* Noise image -> FDCT -> quantised coefficients.  hs,vs in {1,2} are the luma sampling factors (chroma 1x1),
+ * ncomp in {1,3}, quality 1..100 (libjpeg scaling of Annex K.1/K.2), detail 0..3 picks the octave weights (q85 4:2:0: about 0.18 / 0.30 / 0.44 / 0.55 B/px).
+ * Returns 0, -1 bad argument, -2 out of memory. */
+int jds_create(int width, int height, int hs, int vs, int ncomp, int quality, uint64_t seed, int detail,
+               jds_image** out);
+void jds_destroy(jds_image*);
+int jds_mcus(const jds_image*);
+int jds_blocks_per_mcu(const jds_image*);
+/* quantised coefficients, scan order [mcu][block-in-MCU][64], zig-zag order, absolute DC */
+int jds_coefficients(const jds_image*, int16_t* out);
+void jds_quant_tables(const jds_image*, uint8_t* out128);   /* [2][64] natural order */
+/* Entropy-code into a complete baseline JPEG file (malloc'd; release with jds_free_buffer).
+ * restart_interval 0 = no DRI/RSTn; >0 = DRI + RSTn every that many MCUs ("DRI twin": same coefficients). */
+int jds_encode(const jds_image*, int restart_interval, uint8_t** out, size_t* out_len);
+void jds_free_buffer(uint8_t*);
+#ifdef __cplusplus
+}
+#endif
+#endif
