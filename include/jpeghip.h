@@ -1,0 +1,167 @@
+/*
+ * jpeghip.h -- C-ABI of the MI355X-native baseline-JPEG decode path (libjpeghip.so).
+ *
+ * Drop-in boundary behind maxasm/jpeg-decoder's Go marker parser (reference paths are into
+ * /root/reference).  The reference has no FFI of its own; the boundary is the pair of call sites in
+ * decodeStartOfScan:
+ *
+ *   cut 1  main.go:1022-1032  generateCodes + decodeHuffmanData(header, &BitReader{...})
+ *   cut 2  main.go:1054-1057  dequantize; inverseDCT; spreadCoeffecients; convertColorSpace
+ *
+ * jd_decode() replaces both: the Go host marshals Header (main.go:1467-1491) into a jd_frame, hands
+ * over the entropy-coded segment, and gets the cropped RGB8 image that writeBitMap (main.go:1171-1218)
+ * would read out of Header.blocks.  The cgo stub is in INTEGRATION.md and jpeg-decoder_amd/go/.
+ *
+ * Plain C: fixed-width integers, pointers and sizes only.  No call retains a caller pointer after it
+ * returns unless stated.  All functions return 0 on success or a negative JD_E_* code.
+ */
+#ifndef JPEGHIP_H
+#define JPEGHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- frame description: what the Go Header holds at cut 1 ------------------------------------ */
+
+typedef struct jd_component {
+    uint8_t h, v;   /* sampling factors: ColorComponent.hSamplingFactor / vSamplingFactor (main.go:127-128) */
+    uint8_t tq;     /* ColorComponent.qTableId (main.go:131)                                             */
+    uint8_t td, ta; /* dcHuffmanTableId / acHuffmanTableId bound by SOS (main.go:966-973)                */
+} jd_component;
+
+typedef struct jd_huff {
+    uint8_t bits[16];   /* HuffmanTable.codesOfLen (main.go:860-865)                                       */
+    uint8_t vals[256];  /* HuffmanTable.symbols (main.go:866-870)                                          */
+    uint16_t nvals;
+    uint8_t present;
+} jd_huff;
+
+typedef struct jd_frame {
+    uint16_t width, height;       /* Header.width / height (main.go:117-118); precision is fixed at 8     */
+    uint8_t ncomp;                /* 1 or 3 (the reference rejects > 3, main.go:112-115)                  */
+    jd_component comp[3];         /* frame order; component 0 is luma and fixes the MCU (main.go:165)     */
+    uint16_t restart_interval;    /* Header.restartInterval (main.go:830-831); 0 = none                   */
+    uint8_t qt[4][64];            /* QuantizationTable.table: NATURAL order, low byte only (main.go:61-75) */
+    uint8_t qt_present;           /* bit i set = table id i defined                                       */
+    jd_huff huff[2][4];           /* [0][id] = DC tables, [1][id] = AC tables (main.go:850-851)           */
+} jd_frame;
+
+/* ---- error codes -------------------------------------------------------------------------------
+ * The reference prints "Error! ..." and os.Exit(1) (e.g. main.go:189-192); the library returns a code
+ * and the host shim prints jd_strerror() and exits 1 to keep the CLI behaviour. */
+enum {
+    JD_OK = 0,
+    JD_E_ARG = -1,          /* NULL pointer, size mismatch, bad device                                   */
+    JD_E_UNSUPPORTED = -2,  /* sampling other than luma {1,2}x{1,2} / chroma 1x1, ncomp not 1 or 3        */
+    JD_E_TABLE = -3,        /* missing or malformed quantisation / Huffman table                         */
+    JD_E_HIP = -4,          /* HIP runtime error (jd_last_hip_error())                                   */
+    JD_E_NOMEM = -5,
+    JD_E_MARKER = -6,       /* marker other than RSTn inside the entropy-coded segment (main.go:1013-1016) */
+    JD_E_RESTART = -7,      /* number / numbering of RSTn does not match DRI                             */
+    JD_E_HUFFMAN = -8,      /* invalid Huffman code (scanSymbol returned 0xFF, main.go:189-192)           */
+    JD_E_COEF = -9,         /* run/size walks past coefficient 63 (Go: map miss clobbers [0], Appendix C) */
+    JD_E_TRUNCATED = -10,   /* entropy data ended before all MCUs were decoded (readBit -1, main.go:1273)  */
+    JD_E_SYNC = -11,        /* internal: self-synchronising decode failed its consistency check          */
+    JD_E_NOT_INIT = -12,
+    JD_E_STATE = -13        /* batch call out of order (e.g. wait before run)                            */
+};
+const char* jd_strerror(int code);
+int jd_last_hip_error(void);
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* Binds the library to HIP devices (NULL/0 = every visible device).  Replaces nothing in the
+ * reference (it has no device); call once before the first decode.  Thread-safe, idempotent. */
+int jd_init(const int* device_ids, int n_devices);
+void jd_shutdown(void);
+int jd_device_count(void);
+
+/* Validates a frame the way decodeStartOfFrame / decodeStartOfScan + getTable / getQuantizationTable
+ * would need it (main.go:87-180, 432-452, 957-977) without touching the GPU. */
+int jd_frame_check(const jd_frame* frame);
+
+/* Geometry helpers (main.go:159-172): MCU grid and coefficient count for a frame. */
+int jd_frame_geometry(const jd_frame* frame, uint32_t* mcus_x, uint32_t* mcus_y, uint32_t* blocks_per_mcu);
+
+/* ---- one-shot decode: replaces main.go:1022-1032 + 1054-1057 ----------------------------------
+ * ecs            entropy-coded segment, host memory.
+ *                ecs_is_stuffed = 1: the raw bytes between the SOS header and EOI, FF00 stuffing and
+ *                  RSTn markers included (what main.go:993-1021 consumes); the device unstuffs and
+ *                  indexes the restart markers.
+ *                ecs_is_stuffed = 0: the reference's `_bitstream` (main.go:1011,1018): unstuffed, RSTn
+ *                  removed; rst_offsets[k] = byte offset in it where restart interval k+1 starts
+ *                  (n_rst = number of RSTn markers; required when restart_interval > 0).
+ * rgb_out        host memory, height rows of row_stride bytes (>= 3*width), top-down, R,G,B -- the
+ *                crop writeBitMap performs (main.go:1198-1211) without the bottom-up/BGR file order.
+ * Synchronous.  */
+int jd_decode(const jd_frame* frame, const uint8_t* ecs, size_t ecs_len, int ecs_is_stuffed,
+              const uint32_t* rst_offsets, size_t n_rst, uint8_t* rgb_out, size_t row_stride, int device);
+
+/* Parity hook for cut 1 alone (decodeHuffmanData, main.go:749-816): quantised coefficients, int16,
+ * scan order [mcu][block-in-MCU][64] (luma blocks row-major inside the MCU, then Cb, Cr), ZIG-ZAG order,
+ * DC already predicted (absolute), before dequantisation.  coef_cap counts int16 elements. */
+int jd_decode_coefficients(const jd_frame* frame, const uint8_t* ecs, size_t ecs_len, int ecs_is_stuffed,
+                           const uint32_t* rst_offsets, size_t n_rst, int16_t* coef_out, size_t coef_cap,
+                           int device);
+
+/* ---- batch / device-resident form --------------------------------------------------------------
+ * One jd_batch owns the device workspace for n images on one device and decodes all of them with a
+ * fixed sequence of batched kernels (no per-image launches, no host round trips between kernels).
+ * Typical use: create once per shape set, then {upload or bind, run, wait, download} per batch.
+ * The reference decodes files one after another (main.go:1509-1512); this is its throughput form. */
+typedef struct jd_batch jd_batch;
+
+enum {
+    JD_BATCH_KEEP_COEF = 1u   /* keep coefficients readable after run (jd_batch_coefficients)           */
+};
+
+int jd_batch_create(int device, int n_images, const jd_frame* frames, const size_t* ecs_cap,
+                    unsigned flags, jd_batch** out);
+void jd_batch_destroy(jd_batch* b);
+
+/* Input: either copy a stuffed ECS from host memory into the batch's own device buffer ... */
+int jd_batch_upload(jd_batch* b, int image, const uint8_t* ecs, size_t ecs_len);
+/* ... or the reference's unstuffed `_bitstream` + restart offsets (see jd_decode) ... */
+int jd_batch_upload_unstuffed(jd_batch* b, int image, const uint8_t* bitstream, size_t len,
+                              const uint32_t* rst_offsets, size_t n_rst);
+/* ... or point at a stuffed ECS already resident in device memory (not copied; must stay valid until
+ * jd_batch_wait returns).  d_ecs must be 16-byte aligned. */
+int jd_batch_bind_ecs(jd_batch* b, int image, const void* d_ecs, size_t ecs_len);
+/* Output: device memory for image i (height rows of row_stride bytes).  Without a bind the batch
+ * allocates its own RGB buffer (row_stride = 3*width) that jd_batch_download copies out. */
+int jd_batch_bind_rgb(jd_batch* b, int image, void* d_rgb, size_t row_stride);
+
+/* Enqueue the whole decode on `hip_stream` (a hipStream_t; NULL = the batch's own stream).  Does not
+ * block and does not allocate. */
+int jd_batch_run(jd_batch* b, void* hip_stream);
+/* Block until the last run finished; returns the first per-image error (or JD_OK). */
+int jd_batch_wait(jd_batch* b);
+int jd_batch_status(const jd_batch* b, int image);
+int jd_batch_download(jd_batch* b, int image, uint8_t* rgb_out, size_t row_stride);
+int jd_batch_coefficients(jd_batch* b, int image, int16_t* coef_out, size_t coef_cap);
+
+/* Instrumentation for bench.py / DESIGN.md: runs `iters` decodes of the batch on its own stream and
+ * returns, per pipeline stage, the average device time in microseconds measured with hipEvents around
+ * that stage's kernels.  names[i] points at static strings.  Returns the number of stages written. */
+int jd_batch_profile(jd_batch* b, int iters, float* stage_us, const char** names, int cap);
+/* Bytes of device workspace the batch holds, and per-image facts measured by the last run. */
+size_t jd_batch_workspace_bytes(const jd_batch* b);
+int jd_batch_unstuffed_len(jd_batch* b, int image, size_t* len);
+
+/* ---- host-side twin of the Go marker parser (test harness / CLI; Go keeps its own in production) --
+ * Parses a baseline JPEG held in memory the way decodeJPEG and friends do (main.go:1076-1154, 42-180,
+ * 818-888, 942-987) and returns the frame plus the extent of the stuffed entropy-coded segment
+ * (start offset and length, EOI excluded). */
+int jd_parse(const uint8_t* file, size_t file_len, jd_frame* frame, size_t* ecs_off, size_t* ecs_len);
+/* BMP exactly as writeBitMap lays it out (main.go:1171-1218): returns the file size; writes it if
+ * out != NULL and cap is large enough. */
+long jd_bmp_encode(const uint8_t* rgb, size_t row_stride, int width, int height, uint8_t* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

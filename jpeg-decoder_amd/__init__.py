@@ -1,0 +1,312 @@
+"""jpeg-decoder_amd -- Python plumbing over the C-ABI of libjpeghip.so (include/jpeghip.h).
+
+The product is the HIP library; this module only marshals arguments with ctypes for the tests and
+bench.py.  There is NO CPU fallback: importing works without a GPU (so the symbol checks can run), but every
+decode call goes through the HIP kernels and raises if the library or a device is missing.
+
+Function names mirror the reference's Go host (decodeJPEG -> decode_jpeg, writeBitMap -> write_bitmap).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpeghip.so")
+SYNTH_PATH = os.path.join(_HERE, "libjdsynth.so")
+
+_u8, _u16, _u32 = ctypes.c_uint8, ctypes.c_uint16, ctypes.c_uint32
+_vp, _ci, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+
+class Component(ctypes.Structure):
+    _fields_ = [("h", _u8), ("v", _u8), ("tq", _u8), ("td", _u8), ("ta", _u8)]
+
+
+class Huff(ctypes.Structure):
+    _fields_ = [("bits", _u8 * 16), ("vals", _u8 * 256), ("nvals", _u16), ("present", _u8)]
+
+
+class Frame(ctypes.Structure):
+    """jd_frame: what the Go Header holds at cut 1 (main.go:1467-1491)."""
+    _fields_ = [("width", _u16), ("height", _u16), ("ncomp", _u8), ("comp", Component * 3),
+                ("restart_interval", _u16), ("qt", (_u8 * 64) * 4), ("qt_present", _u8),
+                ("huff", (Huff * 4) * 2)]
+
+
+# every symbol include/jpeghip.h declares (tests/test_abi.py checks the library exports exactly these)
+ABI_SYMBOLS = [
+    "jd_strerror", "jd_last_hip_error", "jd_init", "jd_shutdown", "jd_device_count", "jd_frame_check",
+    "jd_frame_geometry", "jd_decode", "jd_decode_coefficients", "jd_batch_create", "jd_batch_destroy",
+    "jd_batch_upload", "jd_batch_upload_unstuffed", "jd_batch_bind_ecs", "jd_batch_bind_rgb", "jd_batch_run",
+    "jd_batch_wait", "jd_batch_status", "jd_batch_download", "jd_batch_coefficients", "jd_batch_profile",
+    "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
+]
+
+
+class JpegHipError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = _lib().jd_strerror(code).decode() if _LIB is not None else "library not loaded"
+        super().__init__("%s: %s (code %d, hip %d)" % (where, msg, code, _lib().jd_last_hip_error()))
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libjpeghip.so is not built (run __graft_entry__.build() or make -C "
+                               "jpeg-decoder_amd/csrc); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        PF = ctypes.POINTER(Frame)
+        L.jd_strerror.restype = ctypes.c_char_p
+        L.jd_strerror.argtypes = [_ci]
+        L.jd_init.argtypes = [ctypes.POINTER(_ci), _ci]
+        L.jd_frame_check.argtypes = [PF]
+        L.jd_frame_geometry.argtypes = [PF, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]
+        L.jd_decode.argtypes = [PF, _vp, _sz, _ci, _vp, _sz, _vp, _sz, _ci]
+        L.jd_decode_coefficients.argtypes = [PF, _vp, _sz, _ci, _vp, _sz, _vp, _sz, _ci]
+        L.jd_batch_create.argtypes = [_ci, _ci, PF, ctypes.POINTER(_sz), ctypes.c_uint, ctypes.POINTER(_vp)]
+        L.jd_batch_destroy.argtypes = [_vp]
+        L.jd_batch_destroy.restype = None
+        L.jd_batch_upload.argtypes = [_vp, _ci, _vp, _sz]
+        L.jd_batch_upload_unstuffed.argtypes = [_vp, _ci, _vp, _sz, _vp, _sz]
+        L.jd_batch_bind_ecs.argtypes = [_vp, _ci, _vp, _sz]
+        L.jd_batch_bind_rgb.argtypes = [_vp, _ci, _vp, _sz]
+        L.jd_batch_run.argtypes = [_vp, _vp]
+        L.jd_batch_wait.argtypes = [_vp]
+        L.jd_batch_status.argtypes = [_vp, _ci]
+        L.jd_batch_download.argtypes = [_vp, _ci, _vp, _sz]
+        L.jd_batch_coefficients.argtypes = [_vp, _ci, _vp, _sz]
+        L.jd_batch_profile.argtypes = [_vp, _ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _ci]
+        L.jd_batch_workspace_bytes.argtypes = [_vp]
+        L.jd_batch_workspace_bytes.restype = _sz
+        L.jd_batch_unstuffed_len.argtypes = [_vp, _ci, ctypes.POINTER(_sz)]
+        L.jd_parse.argtypes = [_vp, _sz, PF, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
+        L.jd_bmp_encode.argtypes = [_vp, _sz, _ci, _ci, _vp, _sz]
+        L.jd_bmp_encode.restype = ctypes.c_long
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise JpegHipError(rc, where)
+
+
+_inited = False
+
+
+def init(devices=None):
+    """jd_init: bind the library to HIP devices (all visible ones by default)."""
+    global _inited
+    if devices is None:
+        rc = _lib().jd_init(None, 0)
+    else:
+        arr = (_ci * len(devices))(*devices)
+        rc = _lib().jd_init(arr, len(devices))
+    _check(rc, "jd_init")
+    _inited = True
+
+
+def _ensure_init():
+    if not _inited:
+        init()
+
+
+def _as_u8(data):
+    a = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+    return a
+
+
+def parse(data):
+    """jd_parse: twin of the Go marker parser (decodeJPEG..., main.go:1076-1154).  -> (Frame, ecs_off, ecs_len)"""
+    a = _as_u8(data)
+    fr, off, ln = Frame(), _sz(), _sz()
+    _check(_lib().jd_parse(a.ctypes.data, a.size, ctypes.byref(fr), ctypes.byref(off), ctypes.byref(ln)), "jd_parse")
+    return fr, off.value, ln.value
+
+
+def geometry(frame):
+    mx, my, bpm = _u32(), _u32(), _u32()
+    _check(_lib().jd_frame_geometry(ctypes.byref(frame), ctypes.byref(mx), ctypes.byref(my), ctypes.byref(bpm)),
+           "jd_frame_geometry")
+    return mx.value, my.value, bpm.value
+
+
+def decode_jpeg(data, device=0):
+    """Parse + jd_decode: the whole of decodeJPEG up to (not including) writeBitMap.  -> H x W x 3 uint8 RGB."""
+    _ensure_init()
+    a = _as_u8(data)
+    fr, off, ln = parse(a)
+    out = np.empty((fr.height, fr.width, 3), np.uint8)
+    _check(_lib().jd_decode(ctypes.byref(fr), a.ctypes.data + off, ln, 1, None, 0, out.ctypes.data, fr.width * 3, device),
+           "jd_decode")
+    return out
+
+
+def decode_unstuffed(frame, bitstream, rst_offsets=(), device=0):
+    """jd_decode with the reference's `_bitstream` (main.go:1011,1018) + restart offsets."""
+    _ensure_init()
+    a = _as_u8(bitstream)
+    r = np.ascontiguousarray(rst_offsets, np.uint32)
+    out = np.empty((frame.height, frame.width, 3), np.uint8)
+    _check(_lib().jd_decode(ctypes.byref(frame), a.ctypes.data, a.size, 0, r.ctypes.data if r.size else None, r.size,
+                            out.ctypes.data, frame.width * 3, device), "jd_decode")
+    return out
+
+
+def decode_coefficients(data, device=0):
+    """jd_decode_coefficients: int16 [mcu][block-in-MCU][64], zig-zag order, absolute DC (cut 1 parity hook)."""
+    _ensure_init()
+    a = _as_u8(data)
+    fr, off, ln = parse(a)
+    mx, my, bpm = geometry(fr)
+    out = np.empty((mx * my, bpm, 64), np.int16)
+    _check(_lib().jd_decode_coefficients(ctypes.byref(fr), a.ctypes.data + off, ln, 1, None, 0, out.ctypes.data, out.size,
+                                         device), "jd_decode_coefficients")
+    return out
+
+
+def write_bitmap(rgb):
+    """jd_bmp_encode: the bytes writeBitMap (main.go:1171-1218) would put in <name>.bmp."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    n = _lib().jd_bmp_encode(None, 0, w, h, None, 0)
+    out = np.empty(n, np.uint8)
+    got = _lib().jd_bmp_encode(rgb.ctypes.data, w * 3, w, h, out.ctypes.data, n)
+    if got != n:
+        raise JpegHipError(int(got), "jd_bmp_encode")
+    return out.tobytes()
+
+
+class Batch:
+    """jd_batch: n images decoded by one fixed sequence of batched kernels on one device."""
+
+    def __init__(self, frames, ecs_caps, device=0, keep_coef=False):
+        _ensure_init()
+        n = len(frames)
+        self.n, self.device = n, device
+        self.frames = (Frame * n)(*frames)
+        caps = (_sz * n)(*[int(c) for c in ecs_caps])
+        h = _vp()
+        _check(_lib().jd_batch_create(device, n, self.frames, caps, 1 if keep_coef else 0, ctypes.byref(h)), "jd_batch_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().jd_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload(self, i, ecs):
+        a = _as_u8(ecs)
+        _check(_lib().jd_batch_upload(self._h, i, a.ctypes.data, a.size), "jd_batch_upload")
+
+    def upload_unstuffed(self, i, bitstream, rst_offsets=()):
+        a = _as_u8(bitstream)
+        r = np.ascontiguousarray(rst_offsets, np.uint32)
+        _check(_lib().jd_batch_upload_unstuffed(self._h, i, a.ctypes.data, a.size, r.ctypes.data if r.size else None, r.size),
+               "jd_batch_upload_unstuffed")
+
+    def bind_ecs(self, i, dev_ptr, length):
+        _check(_lib().jd_batch_bind_ecs(self._h, i, dev_ptr, length), "jd_batch_bind_ecs")
+
+    def bind_rgb(self, i, dev_ptr, row_stride):
+        _check(_lib().jd_batch_bind_rgb(self._h, i, dev_ptr, row_stride), "jd_batch_bind_rgb")
+
+    def run(self, stream=None):
+        _check(_lib().jd_batch_run(self._h, stream), "jd_batch_run")
+
+    def wait(self):
+        _check(_lib().jd_batch_wait(self._h), "jd_batch_wait")
+
+    def status(self, i):
+        return _lib().jd_batch_status(self._h, i)
+
+    def download(self, i):
+        f = self.frames[i]
+        out = np.empty((f.height, f.width, 3), np.uint8)
+        _check(_lib().jd_batch_download(self._h, i, out.ctypes.data, f.width * 3), "jd_batch_download")
+        return out
+
+    def coefficients(self, i):
+        mx, my, bpm = geometry(self.frames[i])
+        out = np.empty((mx * my, bpm, 64), np.int16)
+        _check(_lib().jd_batch_coefficients(self._h, i, out.ctypes.data, out.size), "jd_batch_coefficients")
+        return out
+
+    def profile(self, iters=5):
+        us = (ctypes.c_float * 16)()
+        names = (ctypes.c_char_p * 16)()
+        k = _lib().jd_batch_profile(self._h, iters, us, names, 16)
+        if k < 0:
+            raise JpegHipError(k, "jd_batch_profile")
+        return {names[i].decode(): float(us[i]) for i in range(k)}
+
+    def workspace_bytes(self):
+        return _lib().jd_batch_workspace_bytes(self._h)
+
+    def unstuffed_len(self, i):
+        v = _sz()
+        _check(_lib().jd_batch_unstuffed_len(self._h, i, ctypes.byref(v)), "jd_batch_unstuffed_len")
+        return v.value
+
+
+# ---- synthetic workload maker (libjdsynth.so; host only) ---------------------------------------------------
+_SYN = None
+
+
+def _syn():
+    global _SYN
+    if _SYN is None:
+        if not os.path.exists(SYNTH_PATH):
+            raise RuntimeError("libjdsynth.so is not built")
+        S = ctypes.CDLL(SYNTH_PATH)
+        S.jds_create.argtypes = [_ci] * 6 + [ctypes.c_uint64, _ci, ctypes.POINTER(_vp)]
+        S.jds_encode.argtypes = [_vp, _ci, ctypes.POINTER(ctypes.POINTER(_u8)), ctypes.POINTER(_sz)]
+        S.jds_destroy.argtypes = [_vp]
+        S.jds_destroy.restype = None
+        S.jds_free_buffer.argtypes = [ctypes.POINTER(_u8)]
+        S.jds_free_buffer.restype = None
+        S.jds_mcus.argtypes = [_vp]
+        S.jds_blocks_per_mcu.argtypes = [_vp]
+        S.jds_coefficients.argtypes = [_vp, _vp]
+        _SYN = S
+    return _SYN
+
+
+class SynthImage:
+    """Deterministic noise image -> quantised coefficients; encode() entropy-codes it (DRI twins)."""
+
+    def __init__(self, width, height, hs=2, vs=2, ncomp=3, quality=85, seed=0, detail=2):
+        h = _vp()
+        rc = _syn().jds_create(width, height, hs, vs, ncomp, quality, seed, detail, ctypes.byref(h))
+        if rc:
+            raise ValueError("jds_create failed: %d" % rc)
+        self._h = h
+        self.width, self.height = width, height
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _syn().jds_destroy(self._h)
+            self._h = None
+
+    def coefficients(self):
+        S = _syn()
+        out = np.empty((S.jds_mcus(self._h), S.jds_blocks_per_mcu(self._h), 64), np.int16)
+        S.jds_coefficients(self._h, out.ctypes.data)
+        return out
+
+    def encode(self, restart_interval=0):
+        p, n = ctypes.POINTER(_u8)(), _sz()
+        rc = _syn().jds_encode(self._h, restart_interval, ctypes.byref(p), ctypes.byref(n))
+        if rc:
+            raise ValueError("jds_encode failed: %d" % rc)
+        data = ctypes.string_at(p, n.value)
+        _syn().jds_free_buffer(p)
+        return data

@@ -1,0 +1,590 @@
+// jd_api.cpp -- the C-ABI of include/jpeghip.h: frame validation, workspace planning, table upload and the
+// kernel sequence.  Host code only; the kernels are in jd_kernels.hip.
+//
+// There is no CPU decode path in this library: every entry point that produces coefficients or pixels runs
+// the HIP kernels and fails with JD_E_HIP / JD_E_NOT_INIT when no device is usable.
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/jpeghip.h"
+#include "jd_internal.h"
+#include "jd_tables.h"
+
+extern "C" {
+void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t wgs, hipStream_t s);
+void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
+void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
+                     int flag_slot, hipStream_t s);
+void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
+void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
+void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t max_bpm,
+                            const JdIdctConst& K, hipStream_t s);
+}
+
+namespace {
+
+std::mutex g_mu;
+bool g_init = false;
+std::vector<int> g_devices;
+thread_local int g_last_hip = 0;
+
+#define HIPCHK(expr)                                                   \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) { g_last_hip = (int)e_; return JD_E_HIP; } \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- IDCT constants, main.go:1339-1354 ---------------------------------------------------------------
+// The Go binary computes them at init with its pure-Go math.Cos; the values below are those results (bit
+// patterns listed in SURVEY.md Appendix A.2, Go flavour).  tests/test_host_logic.py checks them against the
+// oracle's independent derivation.
+inline double from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+JdIdctConst idct_constants() {
+    JdIdctConst K;
+    K.M1 = from_bits(0x3ff6a09e667f3bcdull); K.M2 = from_bits(0x3ff1517a7bdb3894ull);
+    K.M3 = from_bits(0x3ff6a09e667f3bcdull); K.M4 = from_bits(0x4004e7ae9144f0fcull);
+    K.M5 = from_bits(0x3fe87de2a6aea964ull);
+    K.S0 = from_bits(0x3fd6a09e667f3bccull); K.S1 = from_bits(0x3fdf6297cff75cb0ull);
+    K.S2 = from_bits(0x3fdd906bcf328d46ull); K.S3 = from_bits(0x3fda9b66290ea1a4ull);
+    K.S4 = from_bits(0x3fd6a09e667f3bcdull); K.S5 = from_bits(0x3fd1c73b39ae68c9ull);
+    K.S6 = from_bits(0x3fc87de2a6aea964ull); K.S7 = from_bits(0x3fb8f8b83c69a60cull);
+    return K;
+}
+
+int status_to_error(uint32_t st) {
+    if (st & JD_ST_MARKER) return JD_E_MARKER;
+    if (st & (JD_ST_RST_COUNT | JD_ST_RST_SEQ)) return JD_E_RESTART;
+    if (st & JD_ST_HUFF) return JD_E_HUFFMAN;
+    if (st & JD_ST_COEF) return JD_E_COEF;
+    if (st & JD_ST_TRUNC) return JD_E_TRUNCATED;
+    if (st & (JD_ST_SYNC | JD_ST_COUNT)) return JD_E_SYNC;
+    return JD_OK;
+}
+
+struct Geometry { uint32_t mcux, mcuy, bpm, hs, vs; };
+
+int frame_geometry(const jd_frame* f, Geometry* g) {
+    if (!f) return JD_E_ARG;
+    if (f->width == 0 || f->height == 0) return JD_E_ARG;
+    if (!(f->ncomp == 1 || f->ncomp == 3)) return JD_E_UNSUPPORTED;
+    uint32_t hs = f->comp[0].h, vs = f->comp[0].v;
+    if (f->ncomp == 1) { hs = 1; vs = 1; }   // single-component scan: 1x1 MCU (luminanceOnlyScan, main.go:753-767)
+    if (!(hs == 1 || hs == 2) || !(vs == 1 || vs == 2)) return JD_E_UNSUPPORTED;
+    for (int c = 1; c < f->ncomp; c++)
+        if (f->comp[c].h != 1 || f->comp[c].v != 1) return JD_E_UNSUPPORTED;   // spreadCoeffecients assumes 1x1
+    g->hs = hs; g->vs = vs;
+    const uint32_t bw = (f->width + 7u) / 8u, bh = (f->height + 7u) / 8u;      // main.go:160-161
+    g->mcux = (bw + hs - 1) / hs; g->mcuy = (bh + vs - 1) / vs;                 // loops at main.go:769-770
+    g->bpm = hs * vs + (f->ncomp - 1u);
+    return JD_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" const char* jd_strerror(int code) {
+    switch (code) {
+    case JD_OK: return "ok";
+    case JD_E_ARG: return "invalid argument";
+    case JD_E_UNSUPPORTED: return "Error! unsupported frame (baseline, 1 or 3 components, luma 1-2 x 1-2, chroma 1x1 only)";
+    case JD_E_TABLE: return "Error! missing or malformed quantisation / Huffman table";
+    case JD_E_HIP: return "HIP runtime error";
+    case JD_E_NOMEM: return "out of memory";
+    case JD_E_MARKER: return "Invalid marker found in the bitsteam";
+    case JD_E_RESTART: return "Error! restart markers do not match the restart interval";
+    case JD_E_HUFFMAN: return "Error! invalid DC Symbols";
+    case JD_E_COEF: return "Error! run/size walks past coefficient 63";
+    case JD_E_TRUNCATED: return "Error! EOF";
+    case JD_E_SYNC: return "internal error: self-synchronising decode did not converge";
+    case JD_E_NOT_INIT: return "jd_init has not been called or found no device";
+    case JD_E_STATE: return "batch call out of order";
+    default: return "unknown error";
+    }
+}
+extern "C" int jd_last_hip_error(void) { return g_last_hip; }
+
+extern "C" int jd_init(const int* device_ids, int n_devices) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) { g_last_hip = (int)e; return JD_E_HIP; }
+    std::vector<int> devs;
+    if (!device_ids || n_devices <= 0) for (int i = 0; i < count; i++) devs.push_back(i);
+    else for (int i = 0; i < n_devices; i++) { if (device_ids[i] < 0 || device_ids[i] >= count) return JD_E_ARG; devs.push_back(device_ids[i]); }
+    g_devices = devs;
+    g_init = true;
+    return JD_OK;
+}
+extern "C" void jd_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); g_init = false; g_devices.clear(); }
+extern "C" int jd_device_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_init ? (int)g_devices.size() : 0; }
+
+extern "C" int jd_frame_geometry(const jd_frame* f, uint32_t* mx, uint32_t* my, uint32_t* bpm) {
+    Geometry g; int rc = frame_geometry(f, &g);
+    if (rc) return rc;
+    if (mx) *mx = g.mcux; if (my) *my = g.mcuy; if (bpm) *bpm = g.bpm;
+    return JD_OK;
+}
+
+extern "C" int jd_frame_check(const jd_frame* f) {
+    Geometry g; int rc = frame_geometry(f, &g);
+    if (rc) return rc;
+    for (int c = 0; c < f->ncomp; c++) {
+        const jd_component& k = f->comp[c];
+        if (k.tq > 3 || !(f->qt_present & (1u << k.tq))) return JD_E_TABLE;       // getQuantizationTable nil (main.go:443-452)
+        if (k.td > 3 || k.ta > 3) return JD_E_TABLE;
+        if (!f->huff[0][k.td].present || !f->huff[1][k.ta].present) return JD_E_TABLE;   // getTable nil (main.go:432-440)
+    }
+    std::vector<uint16_t> scratch;
+    for (int c = 0; c < f->ncomp; c++) {
+        const jd_huff& d = f->huff[0][f->comp[c].td]; const jd_huff& a = f->huff[1][f->comp[c].ta];
+        if (jd_pack_lut(d.bits, d.vals, d.nvals, true, scratch) || jd_pack_lut(a.bits, a.vals, a.nvals, false, scratch)) return JD_E_TABLE;
+    }
+    return JD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct jd_batch {
+    int device = 0, n = 0;
+    unsigned flags = 0;
+    std::vector<jd_frame> frames;
+    std::vector<JdImg> img;                   // host mirror of d_img
+    std::vector<size_t> ecs_cap, own_ecs_off, own_rgb_off;
+    std::vector<uint8_t> rgb_bound;
+    std::vector<uint32_t> status;
+    // device memory
+    JdImg* d_img = nullptr;
+    uint8_t* d_ecs_own = nullptr; uint8_t* d_rgb_own = nullptr; uint8_t* d_stream = nullptr;
+    int16_t* d_coef = nullptr; uint16_t* d_lut = nullptr;
+    uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
+    uint2* d_k0 = nullptr; JdSub* d_sub = nullptr; uint4* d_sync_tot = nullptr;
+    uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_tile = nullptr;
+    std::vector<uint32_t> pre_k0, pre_iv, pre_sync, pre_tile;
+    size_t rgb_own_bytes = 0, stream_bytes = 0, coef_elems = 0, workspace = 0;
+    uint32_t max_lut_bytes = 0, max_bpm = 1;
+    bool dirty = true, ran = false, any_dri = false, any_nodri = false;
+    hipStream_t stream = nullptr, last_stream = nullptr;
+    JdIdctConst K;
+    static const int kSyncFixups = 2;         // fix-up launches enqueued blindly; more only if the flag says so
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, size_t count, size_t* total) {
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    HIPCHK(hipMalloc((void**)p, bytes));
+    *total += bytes;
+    return JD_OK;
+}
+
+JdKernelArgs kernel_args(const jd_batch* b) {
+    JdKernelArgs a;
+    a.imgs = b->d_img; a.n_images = b->n; a.prefix = nullptr; a.stream = b->d_stream; a.coef = b->d_coef;
+    a.lut = b->d_lut; a.status = b->d_status; a.stream_len = b->d_stream_len; a.interval_start = b->d_interval;
+    a.k0_part = b->d_k0; a.sub = b->d_sub; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
+    return a;
+}
+
+// recompute the per-kernel workgroup prefixes from the current ECS lengths and push descriptors
+int refresh(jd_batch* b, hipStream_t s) {
+    const int n = b->n;
+    b->pre_k0.assign(n + 1, 0); b->pre_iv.assign(n + 1, 0); b->pre_sync.assign(n + 1, 0); b->pre_tile.assign(n + 1, 0);
+    for (int i = 0; i < n; i++) {
+        JdImg& im = b->img[i];
+        const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
+        im.n_k0_chunks = stuffed ? (uint32_t)((im.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK) : 0;
+        const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
+        const uint32_t nsw = im.restart_interval ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_WG - 1) / JD_SYNC_WG);
+        b->pre_k0[i + 1] = b->pre_k0[i] + im.n_k0_chunks;
+        b->pre_iv[i + 1] = b->pre_iv[i] + (im.restart_interval ? (im.n_intervals + 63) / 64 : 0);
+        b->pre_sync[i + 1] = b->pre_sync[i] + nsw;
+        b->pre_tile[i + 1] = b->pre_tile[i] + im.n_tiles;
+    }
+    const size_t pb = (size_t)(n + 1) * sizeof(uint32_t);
+    HIPCHK(hipMemcpyAsync(b->d_img, b->img.data(), (size_t)n * sizeof(JdImg), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_pre_k0, b->pre_k0.data(), pb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_pre_iv, b->pre_iv.data(), pb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_pre_sync, b->pre_sync.data(), pb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_pre_tile, b->pre_tile.data(), pb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));          // the host vectors may be rewritten by the next refresh
+    b->dirty = false;
+    return JD_OK;
+}
+
+enum Stage { ST_CLEAR = 0, ST_UNSTUFF, ST_HUFF_DRI, ST_HUFF_SYNC, ST_HUFF_WRITE, ST_IDCT_COLOUR, ST_COUNT_ };
+const char* kStageNames[ST_COUNT_] = { "clear", "unstuff", "huffman_intervals", "huffman_sync", "huffman_write", "idct_colour" };
+
+// enqueue one stage (used by run and by profile)
+int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
+    const JdKernelArgs a = kernel_args(b);
+    const int n = b->n;
+    switch (stage) {
+    case ST_CLEAR:
+        HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)n * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(b->d_coef, 0, b->coef_elems * sizeof(int16_t), s));
+        break;
+    case ST_UNSTUFF:
+        jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[n], s);
+        break;
+    case ST_HUFF_DRI:
+        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[n], b->max_lut_bytes, s);
+        break;
+    case ST_HUFF_SYNC:
+        if (b->pre_sync[n]) {
+            jdk_launch_sync(a, b->d_pre_sync, b->pre_sync[n], b->max_lut_bytes, 0, 0, s);
+            for (int k = 1; k <= jd_batch::kSyncFixups; k++)
+                jdk_launch_sync(a, b->d_pre_sync, b->pre_sync[n], b->max_lut_bytes, 1, k, s);
+            jdk_launch_sync_spine(a, s);
+        }
+        break;
+    case ST_HUFF_WRITE:
+        jdk_launch_write_subseq(a, b->d_pre_sync, b->pre_sync[n], b->max_lut_bytes, s);
+        break;
+    case ST_IDCT_COLOUR:
+        jdk_launch_idct_colour(a, b->d_pre_tile, b->pre_tile[n], b->max_bpm, b->K, s);
+        break;
+    }
+    HIPCHK(hipGetLastError());
+    return JD_OK;
+}
+
+}  // namespace
+
+extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames, const size_t* ecs_cap,
+                               unsigned flags, jd_batch** out) {
+    if (!out) return JD_E_ARG;
+    *out = nullptr;
+    if (!frames || !ecs_cap || n_images <= 0) return JD_E_ARG;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_init) return JD_E_NOT_INIT;
+        if (std::find(g_devices.begin(), g_devices.end(), device) == g_devices.end()) return JD_E_ARG;
+    }
+    for (int i = 0; i < n_images; i++) {
+        int rc = jd_frame_check(&frames[i]);
+        if (rc) return rc;
+        if (ecs_cap[i] == 0 || ecs_cap[i] >= (size_t)1 << 28) return JD_E_ARG;
+    }
+    HIPCHK(hipSetDevice(device));
+    jd_batch* b = new (std::nothrow) jd_batch();
+    if (!b) return JD_E_NOMEM;
+    b->device = device; b->n = n_images; b->flags = flags; b->K = idct_constants();
+    b->frames.assign(frames, frames + n_images);
+    b->img.resize(n_images); b->ecs_cap.assign(ecs_cap, ecs_cap + n_images);
+    b->own_ecs_off.resize(n_images); b->own_rgb_off.resize(n_images); b->rgb_bound.assign(n_images, 0);
+    b->status.assign(n_images, 0);
+
+    // ---- Huffman table sets, de-duplicated across the batch -----------------------------------------
+    std::vector<uint16_t> lut;
+    std::map<std::string, std::pair<uint32_t, uint32_t>> seen;   // serialised tables -> (offset, length)
+    size_t ecs_own = 0, rgb_own = 0, stream = 0, coef = 0;
+    uint32_t k0c = 0, ivb = 0, subb = 0, swb = 0, tileb = 0;
+    for (int i = 0; i < n_images; i++) {
+        const jd_frame& f = frames[i];
+        JdImg& im = b->img[i];
+        memset(&im, 0, sizeof im);
+        Geometry g; frame_geometry(&f, &g);
+        im.width = f.width; im.height = f.height; im.mcux = g.mcux; im.mcuy = g.mcuy; im.n_mcus = g.mcux * g.mcuy;
+        im.hs = g.hs; im.vs = g.vs; im.ncomp = f.ncomp; im.bpm = g.bpm;
+        im.restart_interval = f.restart_interval;
+        im.n_intervals = f.restart_interval ? (im.n_mcus + f.restart_interval - 1) / f.restart_interval : 1;
+        b->max_bpm = std::max(b->max_bpm, g.bpm);
+        if (f.restart_interval) b->any_dri = true; else b->any_nodri = true;
+        // table set: per component (td, ta); identical (class,id) pairs share one packed table
+        std::string key;
+        std::vector<uint16_t> set;
+        std::map<int, uint32_t> placed;                           // class*4+id -> entry offset in set
+        for (int c = 0; c < f.ncomp; c++) {
+            for (int cls = 0; cls < 2; cls++) {
+                const int id = cls ? f.comp[c].ta : f.comp[c].td;
+                const jd_huff& h = f.huff[cls][id];
+                auto it = placed.find(cls * 4 + id);
+                if (it == placed.end()) {
+                    const uint32_t off = (uint32_t)set.size();
+                    if (jd_pack_lut(h.bits, h.vals, h.nvals, cls == 0, set)) { delete b; return JD_E_TABLE; }
+                    it = placed.emplace(cls * 4 + id, off).first;
+                    key.append((const char*)h.bits, 16); key.append((const char*)h.vals, h.nvals); key.push_back((char)(cls * 4 + id));
+                }
+                (cls ? im.ac_lut : im.dc_lut)[c] = it->second;
+            }
+            key.push_back((char)(0x40 | (f.comp[c].td << 2) | f.comp[c].ta));
+            memcpy(im.q[c], f.qt[f.comp[c].tq], 64);
+        }
+        while (set.size() % 8) set.push_back(0);
+        auto sit = seen.find(key);
+        if (sit == seen.end()) {
+            sit = seen.emplace(key, std::make_pair((uint32_t)lut.size(), (uint32_t)set.size())).first;
+            lut.insert(lut.end(), set.begin(), set.end());
+        }
+        im.lut_off = sit->second.first; im.lut_len = sit->second.second;
+        b->max_lut_bytes = std::max<uint32_t>(b->max_lut_bytes, im.lut_len * 2u);
+        // workspace slices
+        b->own_ecs_off[i] = ecs_own; ecs_own += align_up(ecs_cap[i] + 16, 256);
+        b->own_rgb_off[i] = rgb_own; rgb_own += align_up((size_t)f.width * 3 * f.height, 256);
+        im.stream_off = stream; stream += align_up(JD_STREAM_FRONT + ecs_cap[i] + JD_STREAM_TAIL, 256);
+        im.coef_off = coef; coef += (size_t)im.n_mcus * im.bpm * 64;
+        im.k0_chunk_base = k0c; k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);
+        im.interval_base = ivb; ivb += im.n_intervals + 1;
+        im.n_subseq_cap = (uint32_t)(((uint64_t)ecs_cap[i] * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
+        im.n_sync_wg = f.restart_interval ? 0 : (im.n_subseq_cap + JD_SYNC_WG - 1) / JD_SYNC_WG;
+        im.subseq_base = subb; subb += f.restart_interval ? 0 : im.n_sync_wg * JD_SYNC_WG;
+        im.sync_wg_base = swb; swb += im.n_sync_wg;
+        im.n_tiles = (im.n_mcus + JD_TILE_MCUS - 1) / JD_TILE_MCUS; im.tile_base = tileb; tileb += im.n_tiles;
+        im.row_stride = (uint32_t)f.width * 3;
+        im.ecs_len = 0;
+    }
+    if (b->max_lut_bytes > 150 * 1024) { delete b; return JD_E_TABLE; }
+    b->rgb_own_bytes = rgb_own; b->stream_bytes = stream; b->coef_elems = coef;
+
+    size_t tot = 0;
+    int rc = JD_OK;
+    auto A = [&](int r) { if (rc == JD_OK) rc = r; };
+    A(dev_alloc(&b->d_img, (size_t)n_images, &tot));
+    A(dev_alloc(&b->d_ecs_own, ecs_own, &tot));
+    A(dev_alloc(&b->d_rgb_own, rgb_own, &tot));
+    A(dev_alloc(&b->d_stream, stream, &tot));
+    A(dev_alloc(&b->d_coef, coef, &tot));
+    A(dev_alloc(&b->d_lut, lut.size(), &tot));
+    A(dev_alloc(&b->d_status, (size_t)n_images, &tot));
+    A(dev_alloc(&b->d_stream_len, (size_t)n_images, &tot));
+    A(dev_alloc(&b->d_interval, (size_t)ivb, &tot));
+    A(dev_alloc(&b->d_changed, (size_t)64, &tot));
+    A(dev_alloc(&b->d_k0, (size_t)k0c, &tot));
+    A(dev_alloc(&b->d_sub, (size_t)subb, &tot));
+    A(dev_alloc(&b->d_sync_tot, (size_t)swb, &tot));
+    A(dev_alloc(&b->d_pre_k0, (size_t)n_images + 1, &tot));
+    A(dev_alloc(&b->d_pre_iv, (size_t)n_images + 1, &tot));
+    A(dev_alloc(&b->d_pre_sync, (size_t)n_images + 1, &tot));
+    A(dev_alloc(&b->d_pre_tile, (size_t)n_images + 1, &tot));
+    if (rc == JD_OK && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) rc = JD_E_HIP;
+    if (rc == JD_OK && hipMemcpy(b->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) rc = JD_E_HIP;
+    if (rc == JD_OK && hipMemset(b->d_stream, 0, std::max<size_t>(stream, 256)) != hipSuccess) rc = JD_E_HIP;
+    if (rc != JD_OK) { jd_batch_destroy(b); return rc == JD_E_HIP && g_last_hip == (int)hipErrorOutOfMemory ? JD_E_NOMEM : rc; }
+    b->workspace = tot;
+    for (int i = 0; i < n_images; i++) {
+        b->img[i].ecs = b->d_ecs_own + b->own_ecs_off[i];
+        b->img[i].rgb = b->d_rgb_own + b->own_rgb_off[i];
+    }
+    *out = b;
+    return JD_OK;
+}
+
+extern "C" void jd_batch_destroy(jd_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    void* ptrs[] = { b->d_img, b->d_ecs_own, b->d_rgb_own, b->d_stream, b->d_coef, b->d_lut, b->d_status, b->d_stream_len,
+                     b->d_interval, b->d_changed, b->d_k0, b->d_sub, b->d_sync_tot, b->d_pre_k0, b->d_pre_iv, b->d_pre_sync,
+                     b->d_pre_tile };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete b;
+}
+
+static int check_image(const jd_batch* b, int image) { return (!b || image < 0 || image >= b->n) ? JD_E_ARG : JD_OK; }
+
+extern "C" int jd_batch_upload(jd_batch* b, int image, const uint8_t* ecs, size_t ecs_len) {
+    if (check_image(b, image) || !ecs) return JD_E_ARG;
+    if (ecs_len == 0 || ecs_len > b->ecs_cap[image]) return JD_E_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    uint8_t* dst = b->d_ecs_own + b->own_ecs_off[image];
+    HIPCHK(hipMemcpyAsync(dst, ecs, ecs_len, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));            // caller's buffer is free again on return (cgo rule)
+    JdImg& im = b->img[image];
+    im.ecs = dst; im.ecs_len = (uint32_t)ecs_len; im.flags &= ~JD_IMG_UNSTUFFED_INPUT;
+    b->dirty = true;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_upload_unstuffed(jd_batch* b, int image, const uint8_t* bs, size_t len,
+                                         const uint32_t* rst_offsets, size_t n_rst) {
+    if (check_image(b, image) || !bs) return JD_E_ARG;
+    if (len == 0 || len > b->ecs_cap[image]) return JD_E_ARG;
+    JdImg& im = b->img[image];
+    if (n_rst != (size_t)im.n_intervals - 1) return JD_E_RESTART;
+    if (n_rst && !rst_offsets) return JD_E_ARG;
+    std::vector<uint32_t> iv(im.n_intervals + 1);
+    iv[0] = 0; iv[im.n_intervals] = (uint32_t)len;
+    for (size_t k = 0; k < n_rst; k++) {
+        if (rst_offsets[k] > len || (k && rst_offsets[k] < rst_offsets[k - 1])) return JD_E_RESTART;
+        iv[k + 1] = rst_offsets[k];
+    }
+    HIPCHK(hipSetDevice(b->device));
+    const uint32_t l32 = (uint32_t)len;
+    HIPCHK(hipMemcpyAsync(b->d_stream + im.stream_off + JD_STREAM_FRONT, bs, len, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_interval + im.interval_base, iv.data(), iv.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_stream_len + image, &l32, 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    im.ecs_len = l32; im.flags |= JD_IMG_UNSTUFFED_INPUT;
+    b->dirty = true;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_bind_ecs(jd_batch* b, int image, const void* d_ecs, size_t ecs_len) {
+    if (check_image(b, image) || !d_ecs) return JD_E_ARG;
+    if (ecs_len == 0 || ecs_len > b->ecs_cap[image] || ((uintptr_t)d_ecs & 15)) return JD_E_ARG;
+    JdImg& im = b->img[image];
+    im.ecs = (const uint8_t*)d_ecs; im.ecs_len = (uint32_t)ecs_len; im.flags &= ~JD_IMG_UNSTUFFED_INPUT;
+    b->dirty = true;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_bind_rgb(jd_batch* b, int image, void* d_rgb, size_t row_stride) {
+    if (check_image(b, image) || !d_rgb) return JD_E_ARG;
+    JdImg& im = b->img[image];
+    if (row_stride < (size_t)im.width * 3 || row_stride > 0xFFFFFFFFu) return JD_E_ARG;
+    im.rgb = (uint8_t*)d_rgb; im.row_stride = (uint32_t)row_stride; b->rgb_bound[image] = 1;
+    b->dirty = true;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_run(jd_batch* b, void* hip_stream) {
+    if (!b) return JD_E_ARG;
+    for (int i = 0; i < b->n; i++) if (b->img[i].ecs_len == 0) return JD_E_STATE;
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+    if (b->dirty) { int rc = refresh(b, s); if (rc) return rc; }
+    for (int st = 0; st < ST_COUNT_; st++) { int rc = enqueue_stage(b, st, s); if (rc) return rc; }
+    b->last_stream = s; b->ran = true;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_wait(jd_batch* b) {
+    if (!b) return JD_E_ARG;
+    if (!b->ran) return JD_E_STATE;
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = b->last_stream;
+    HIPCHK(hipStreamSynchronize(s));
+    uint32_t changed[64];
+    HIPCHK(hipMemcpy(changed, b->d_changed, sizeof changed, hipMemcpyDeviceToHost));
+    if (changed[jd_batch::kSyncFixups]) {
+        // Rare: a sub-sequence chain crossed more workgroup boundaries than the blind fix-ups cover.  Keep
+        // fixing up until no workgroup's exit state moves, then redo the stages that consumed the result.
+        const JdKernelArgs a = kernel_args(b);
+        int guard = 0;
+        do {
+            HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
+            jdk_launch_sync(a, b->d_pre_sync, b->pre_sync[b->n], b->max_lut_bytes, 1, 1, s);
+            HIPCHK(hipMemcpyAsync(changed, b->d_changed, sizeof changed, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        } while (changed[1] && ++guard < 100000);
+        // clear only the sync-related status bits and the coefficients, then re-run the consumers
+        HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(b->d_coef, 0, b->coef_elems * sizeof(int16_t), s));
+        jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[b->n], s);          // restores K0 status bits (idempotent)
+        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[b->n], b->max_lut_bytes, s);
+        jdk_launch_sync_spine(a, s);
+        int rc = enqueue_stage(b, ST_HUFF_WRITE, s); if (rc) return rc;
+        rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    HIPCHK(hipMemcpy(b->status.data(), b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < b->n; i++) { int e = status_to_error(b->status[i]); if (e) return e; }
+    return JD_OK;
+}
+
+extern "C" int jd_batch_status(const jd_batch* b, int image) {
+    if (check_image(b, image)) return JD_E_ARG;
+    return status_to_error(b->status[image]);
+}
+
+extern "C" int jd_batch_download(jd_batch* b, int image, uint8_t* rgb_out, size_t row_stride) {
+    if (check_image(b, image) || !rgb_out) return JD_E_ARG;
+    const JdImg& im = b->img[image];
+    if (row_stride < (size_t)im.width * 3) return JD_E_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpy2D(rgb_out, row_stride, im.rgb, im.row_stride, (size_t)im.width * 3, im.height, hipMemcpyDeviceToHost));
+    return JD_OK;
+}
+
+extern "C" int jd_batch_coefficients(jd_batch* b, int image, int16_t* out, size_t cap) {
+    if (check_image(b, image) || !out) return JD_E_ARG;
+    const JdImg& im = b->img[image];
+    const size_t n = (size_t)im.n_mcus * im.bpm * 64;
+    if (cap < n) return JD_E_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpy(out, b->d_coef + im.coef_off, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return JD_OK;
+}
+
+extern "C" size_t jd_batch_workspace_bytes(const jd_batch* b) { return b ? b->workspace : 0; }
+
+extern "C" int jd_batch_unstuffed_len(jd_batch* b, int image, size_t* len) {
+    if (check_image(b, image) || !len) return JD_E_ARG;
+    uint32_t v = 0;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpy(&v, b->d_stream_len + image, 4, hipMemcpyDeviceToHost));
+    *len = v;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_profile(jd_batch* b, int iters, float* stage_us, const char** names, int cap) {
+    if (!b || !stage_us || iters <= 0 || cap < ST_COUNT_) return JD_E_ARG;
+    for (int i = 0; i < b->n; i++) if (b->img[i].ecs_len == 0) return JD_E_STATE;
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = b->stream;
+    if (b->dirty) { int rc = refresh(b, s); if (rc) return rc; }
+    hipEvent_t ev[ST_COUNT_ + 1];
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    std::vector<double> acc(ST_COUNT_, 0.0);
+    for (int it = 0; it < iters; it++) {
+        HIPCHK(hipEventRecord(ev[0], s));
+        for (int st = 0; st < ST_COUNT_; st++) {
+            int rc = enqueue_stage(b, st, s); if (rc) return rc;
+            HIPCHK(hipEventRecord(ev[st + 1], s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        for (int st = 0; st < ST_COUNT_; st++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[st], ev[st + 1])); acc[st] += ms * 1000.0; }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int st = 0; st < ST_COUNT_; st++) { stage_us[st] = (float)(acc[st] / iters); if (names) names[st] = kStageNames[st]; }
+    b->last_stream = s; b->ran = true;
+    return ST_COUNT_;
+}
+
+// ---- one-shot forms ----------------------------------------------------------------------------------
+static int one_shot(const jd_frame* frame, const uint8_t* ecs, size_t ecs_len, int stuffed, const uint32_t* rst,
+                    size_t n_rst, int device, unsigned flags, jd_batch** out) {
+    if (!frame || !ecs || ecs_len == 0) return JD_E_ARG;
+    jd_batch* b = nullptr;
+    int rc = jd_batch_create(device, 1, frame, &ecs_len, flags, &b);
+    if (rc) return rc;
+    rc = stuffed ? jd_batch_upload(b, 0, ecs, ecs_len) : jd_batch_upload_unstuffed(b, 0, ecs, ecs_len, rst, n_rst);
+    if (!rc) rc = jd_batch_run(b, nullptr);
+    if (!rc) rc = jd_batch_wait(b);
+    if (rc) { jd_batch_destroy(b); return rc; }
+    *out = b;
+    return JD_OK;
+}
+
+extern "C" int jd_decode(const jd_frame* frame, const uint8_t* ecs, size_t ecs_len, int ecs_is_stuffed,
+                         const uint32_t* rst_offsets, size_t n_rst, uint8_t* rgb_out, size_t row_stride, int device) {
+    if (!rgb_out) return JD_E_ARG;
+    jd_batch* b = nullptr;
+    int rc = one_shot(frame, ecs, ecs_len, ecs_is_stuffed, rst_offsets, n_rst, device, 0, &b);
+    if (rc) return rc;
+    rc = jd_batch_download(b, 0, rgb_out, row_stride);
+    jd_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int jd_decode_coefficients(const jd_frame* frame, const uint8_t* ecs, size_t ecs_len, int ecs_is_stuffed,
+                                      const uint32_t* rst_offsets, size_t n_rst, int16_t* coef_out, size_t coef_cap,
+                                      int device) {
+    if (!coef_out) return JD_E_ARG;
+    jd_batch* b = nullptr;
+    int rc = one_shot(frame, ecs, ecs_len, ecs_is_stuffed, rst_offsets, n_rst, device, JD_BATCH_KEEP_COEF, &b);
+    if (rc) return rc;
+    rc = jd_batch_coefficients(b, 0, coef_out, coef_cap);
+    jd_batch_destroy(b);
+    return rc;
+}

@@ -1,0 +1,105 @@
+// jd_internal.h -- shared between the host API (jd_api.hip) and the kernels (jd_kernels.hip).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+
+// ---- Huffman lookup tables -------------------------------------------------------------------------
+// One table = JD_LUT_PRIMARY u16 entries indexed by the next JD_LUT_BITS bits of the stream, followed by
+// 64-entry secondary tables for codes longer than JD_LUT_BITS (indexed by the following 6 bits).
+//   bit 15 = 0 : [4:0] total bits consumed (code length + magnitude bits), [8:5] magnitude bit count,
+//                [14:9] zig-zag advance - 1 (run for run/size symbols, 15 for ZRL, 63 for EOB, 0 for DC)
+//   bit 15 = 1 : [14:0] offset (in entries, from the table start) of the secondary table
+//   0          : no code starts with these bits (invalid)
+#define JD_LUT_BITS 10
+#define JD_LUT_PRIMARY (1 << JD_LUT_BITS)
+#define JD_LUT_SECONDARY 64
+
+// self-synchronising decode: bits per sub-sequence (one lane each)
+#define JD_SUBSEQ_BITS 1024u
+#define JD_SYNC_WG 256
+
+// unstuff pass: bytes per workgroup
+#define JD_K0_THREADS 256
+#define JD_K0_CHUNK (JD_K0_THREADS * 16)
+
+// unstuffed stream: bytes of padding in front of / behind each image's data
+#define JD_STREAM_FRONT 16
+#define JD_STREAM_TAIL 48
+
+// IDCT + colour kernel: MCUs per workgroup (one wave per block-in-MCU, one lane per MCU)
+#define JD_TILE_MCUS 64
+
+// per-image status bits written by the kernels
+enum {
+    JD_ST_MARKER = 1u << 0,      // non-RST marker inside the ECS
+    JD_ST_RST_COUNT = 1u << 1,   // number of RSTn != intervals - 1
+    JD_ST_RST_SEQ = 1u << 2,     // RSTn numbering out of sequence
+    JD_ST_HUFF = 1u << 3,        // invalid Huffman code
+    JD_ST_COEF = 1u << 4,        // coefficient index ran past 63
+    JD_ST_TRUNC = 1u << 5,       // data ended early / interval overrun
+    JD_ST_SYNC = 1u << 6,        // sync result inconsistent
+    JD_ST_COUNT = 1u << 7        // decoded block count != expected
+};
+
+enum { JD_IMG_UNSTUFFED_INPUT = 1u };   // flags: K0 is skipped, host filled stream + interval table
+
+struct JdImg {
+    const uint8_t* ecs;          // stuffed ECS (device)
+    uint8_t* rgb;                // output image (device)
+    uint32_t ecs_len;
+    uint32_t row_stride;
+    uint32_t width, height;
+    uint32_t mcux, mcuy, n_mcus;
+    uint32_t hs, vs, ncomp, bpm; // bpm = blocks per MCU
+    uint32_t restart_interval, n_intervals;
+    uint32_t flags;
+    uint32_t k0_chunk_base, n_k0_chunks;
+    uint32_t interval_base;      // index into interval_start[] (n_intervals + 1 entries)
+    uint32_t subseq_base, n_subseq_cap, sync_wg_base, n_sync_wg;
+    uint32_t lut_off, lut_len;   // u16 offset / length of this image's table set in the LUT buffer
+    uint32_t dc_lut[3], ac_lut[3]; // per component: entry offset of its DC / AC table inside the set
+    uint32_t tile_base, n_tiles; // IDCT/colour tiles
+    uint32_t pad0;
+    uint64_t stream_off;         // byte offset of this image's region in the unstuffed buffer
+    uint64_t coef_off;           // int16 offset in the coefficient buffer
+    uint8_t q[3][64];            // quantisation table per component, natural order
+};
+
+struct JdIdctConst {             // main.go:1339-1354
+    double M1, M2, M3, M4, M5, S0, S1, S2, S3, S4, S5, S6, S7;
+};
+
+// per-sub-sequence record of the self-synchronising pass
+struct JdSub {
+    uint32_t entry;              // packed entry state used for the last decode of this sub-sequence
+    uint32_t exit;               // packed exit state (entry of the next sub-sequence)
+    uint32_t n;                  // coefficient slots advanced
+    int32_t dc[3];               // sum of DC differences per component
+};
+// packed state: [7:0] bit offset past the sub-sequence start, [15:8] block-in-MCU, [23:16] zig-zag index,
+// bit 31 = valid
+#define JD_STATE_VALID 0x80000000u
+
+struct JdKernelArgs {
+    const JdImg* imgs;
+    int n_images;
+    const uint32_t* prefix;      // n_images + 1 exclusive prefix of workgroups per image for this kernel
+    uint8_t* stream;             // unstuffed streams
+    int16_t* coef;
+    const uint16_t* lut;
+    uint32_t* status;            // per image
+    uint32_t* stream_len;        // per image: unstuffed byte count
+    uint32_t* interval_start;
+    uint2* k0_part;              // per K0 chunk: (kept bytes, RST markers) -> exclusive prefix after spine
+    JdSub* sub;
+    uint4* sync_tot;             // per sync workgroup: (n, dc0, dc1, dc2) totals -> exclusive prefix after spine
+    uint32_t* changed;           // sync: set when a workgroup's exit state changed
+};
+
+// Launchers (jd_kernels.hip).  All are asynchronous on `stream`.
+struct JdLaunchPlan {
+    uint32_t k0_wgs, sync_wgs, interval_wgs, tile_wgs;
+    uint32_t max_lut_bytes;
+    int any_stuffed, any_dri, any_nodri;
+};

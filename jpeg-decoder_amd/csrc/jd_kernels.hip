@@ -1,0 +1,677 @@
+// jd_kernels.hip -- CDNA4 (gfx950) kernels of the baseline-JPEG decode path.
+//
+//   K0  k0_count / k0_spine / k0_scatter   unstuff FF00, drop + index RSTn      (main.go:993-1021)
+//   K1  k1_sync / k1_sync_spine            self-synchronising sub-sequence pass (no DRI)
+//       k1_write_intervals / _subseq       Huffman decode -> int16 coefficients (main.go:749-816, 186-240,
+//                                          1156-1169, 1252-1316)
+//   K2  k2_idct_colour                     dequantise + de-zigzag + fp64 truncating IDCT + chroma spread +
+//                                          float32 YCbCr->RGB (main.go:638-666, 454-606, 710-747, 669-707;
+//                                          zmap/map.go:3-68)
+//
+// Compiled with -ffp-contract=off: the IDCT and the colour conversion reproduce separately rounded
+// IEEE operations.  All kernels are batched: a workgroup finds its image through an
+// exclusive prefix of workgroups-per-image.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jd_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_image(const uint32_t* __restrict__ prefix, int n, uint32_t wg) {
+    int lo = 0, hi = n;                       // prefix[lo] <= wg < prefix[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= wg) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a 256-thread block; `tmp` has >= 8 words of LDS; returns block total in `total`
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) tmp[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; w++) { uint32_t t = tmp[w]; if (w < wv) base += t; tot += t; }
+    total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: unstuff + restart index
+// Byte rule (T.81 B.1.1.5, what main.go:993-1021 does byte by byte):
+//   FF followed by 00      -> keep FF, drop 00
+//   FF followed by D0..D7  -> drop both, restart boundary
+//   FF followed by FF      -> fill byte, drop the first FF
+//   FF followed by other   -> marker inside the segment: error (main.go:1013-1016)
+// ------------------------------------------------------------------------------------------------
+struct K0Bytes { uint32_t w[4]; uint32_t prev, next; uint32_t n; };
+
+__device__ __forceinline__ uint32_t k0_byte(const K0Bytes& b, int j) { return (b.w[j >> 2] >> ((j & 3) * 8)) & 0xFF; }
+
+__device__ __forceinline__ void k0_load(const uint8_t* __restrict__ ecs, uint32_t len, uint32_t g0, K0Bytes& b) {
+    b.n = g0 < len ? (len - g0 < 16 ? len - g0 : 16) : 0;
+    b.w[0] = b.w[1] = b.w[2] = b.w[3] = 0;
+    if (b.n == 16) {
+        uint4 v = *reinterpret_cast<const uint4*>(ecs + g0);
+        b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+    } else {
+        for (uint32_t j = 0; j < b.n; j++) b.w[j >> 2] |= (uint32_t)ecs[g0 + j] << ((j & 3) * 8);
+    }
+    b.prev = (g0 > 0 && b.n) ? ecs[g0 - 1] : 0;
+    b.next = (g0 + 16 < len) ? ecs[g0 + 16] : 0xD9;      // past the segment: behaves like EOI
+}
+
+// keep / rst / bad masks (bit j = byte j of this thread)
+__device__ __forceinline__ void k0_classify(const K0Bytes& b, uint32_t& keep, uint32_t& rst, uint32_t& bad) {
+    keep = rst = bad = 0;
+    uint32_t p = b.prev;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t c = k0_byte(b, j);
+        uint32_t nx = (j < 15) ? k0_byte(b, j + 1) : b.next;
+        if ((uint32_t)j + 1 == b.n) nx = b.next;
+        if ((uint32_t)j < b.n) {
+            if (c == 0xFF) {
+                if (nx == 0x00) keep |= 1u << j;
+            } else if (p == 0xFF) {
+                if (c == 0x00) { /* stuffing */ }
+                else if (c >= 0xD0 && c <= 0xD7) rst |= 1u << j;
+                else bad |= 1u << j;
+            } else keep |= 1u << j;
+        }
+        p = c;
+    }
+}
+
+__global__ __launch_bounds__(JD_K0_THREADS) void k0_count(JdKernelArgs a) {
+    __shared__ uint32_t red[16];
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    const uint32_t chunk = blockIdx.x - a.prefix[img];
+    const uint32_t g0 = chunk * JD_K0_CHUNK + threadIdx.x * 16;
+    K0Bytes b; k0_load(im.ecs, im.ecs_len, g0, b);
+    uint32_t keep, rst, bad; k0_classify(b, keep, rst, bad);
+    uint32_t v = __popc(keep) | (__popc(rst) << 16);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) red[wv] = v;
+    if (__any(bad != 0) && lane == 0) atomicOr(&a.status[img], JD_ST_MARKER);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = red[0] + red[1] + red[2] + red[3];
+        a.k0_part[im.k0_chunk_base + chunk] = make_uint2(t & 0xFFFF, t >> 16);
+    }
+}
+
+// one workgroup per image: exclusive prefix over its chunks, stream length, marker count check
+__global__ __launch_bounds__(256) void k0_spine(JdKernelArgs a) {
+    __shared__ uint32_t tmp[8];
+    const int img = blockIdx.x;
+    const JdImg& im = a.imgs[img];
+    if (im.flags & JD_IMG_UNSTUFFED_INPUT) return;
+    uint32_t run_k = 0, run_r = 0;
+    for (uint32_t c0 = 0; c0 < im.n_k0_chunks; c0 += 256) {
+        const uint32_t c = c0 + threadIdx.x;
+        uint2 v = c < im.n_k0_chunks ? a.k0_part[im.k0_chunk_base + c] : make_uint2(0, 0);
+        uint32_t tk, tr;
+        uint32_t ek = block_excl_scan(v.x, tmp, tk);
+        uint32_t er = block_excl_scan(v.y, tmp, tr);
+        if (c < im.n_k0_chunks) a.k0_part[im.k0_chunk_base + c] = make_uint2(run_k + ek, run_r + er);
+        run_k += tk; run_r += tr;
+    }
+    if (threadIdx.x == 0) {
+        a.stream_len[img] = run_k;
+        a.interval_start[im.interval_base] = 0;
+        a.interval_start[im.interval_base + im.n_intervals] = run_k;
+        if (run_r != im.n_intervals - 1) atomicOr(&a.status[img], JD_ST_RST_COUNT);
+    }
+}
+
+__global__ __launch_bounds__(JD_K0_THREADS) void k0_scatter(JdKernelArgs a) {
+    __shared__ uint32_t tmp[8];
+    __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 16];
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    const uint32_t chunk = blockIdx.x - a.prefix[img];
+    const uint32_t g0 = chunk * JD_K0_CHUNK + threadIdx.x * 16;
+    K0Bytes b; k0_load(im.ecs, im.ecs_len, g0, b);
+    uint32_t keep, rst, bad; k0_classify(b, keep, rst, bad);
+    const uint2 base = a.k0_part[im.k0_chunk_base + chunk];     // exclusive prefix within the image
+    uint32_t tk, tr;
+    const uint32_t ek = block_excl_scan(__popc(keep), tmp, tk);
+    const uint32_t er = block_excl_scan(__popc(rst), tmp, tr);
+    const uint32_t al = base.x & 3;                              // keep LDS and global dword phases equal
+    uint32_t o = al + ek;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (keep & (1u << j)) buf[o++] = (uint8_t)k0_byte(b, j);
+    }
+    if (rst) {
+        uint32_t ridx = base.y + er;                             // markers before this thread
+        for (int j = 0; j < 16; j++) {
+            if (rst & (1u << j)) {
+                const uint32_t k = ridx + 1;                     // interval that starts after this marker
+                const uint32_t off = base.x + ek + __popc(keep & ((1u << j) - 1));
+                if (k < im.n_intervals) a.interval_start[im.interval_base + k] = off;
+                if ((k0_byte(b, j) & 7) != (ridx & 7)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
+                ridx++;
+            }
+        }
+    }
+    __syncthreads();
+    uint8_t* dst = a.stream + im.stream_off + JD_STREAM_FRONT + (base.x - al);   // dword aligned
+    const uint32_t lo = al, hi = al + tk;                        // valid byte range in buf
+    const uint32_t dlo = (lo + 3) >> 2, dhi = hi >> 2;           // full dwords [dlo, dhi)
+    for (uint32_t d = dlo + threadIdx.x; d < dhi; d += JD_K0_THREADS)
+        reinterpret_cast<uint32_t*>(dst)[d] = reinterpret_cast<const uint32_t*>(buf)[d];
+    if (threadIdx.x < 8) {                                       // ragged head / tail bytes
+        uint32_t i;
+        if (threadIdx.x < 4) { i = lo + threadIdx.x; if (i < hi && i < (dlo << 2)) dst[i] = buf[i]; }
+        else {
+            uint32_t t0 = dhi << 2; if (t0 < (dlo << 2)) t0 = dlo << 2;
+            i = t0 + (threadIdx.x - 4);
+            if (i >= lo && i < hi) dst[i] = buf[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: Huffman decode core
+// ------------------------------------------------------------------------------------------------
+struct Cursor {
+    const uint32_t* W;     // dword 0 of the image's unstuffed data (JD_STREAM_FRONT bytes readable before it)
+    int di;                // dword index held in w0
+    uint32_t w0, w1, nxt;  // big-endian dwords di, di+1, di+2
+    uint32_t o;            // bits of w0 already consumed, kept in [1,32]
+    uint32_t pos;          // absolute bit position
+};
+
+__device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
+
+__device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* W, uint32_t pbit) {
+    c.W = W; c.pos = pbit;
+    c.o = ((pbit - 1u) & 31u) + 1u;
+    c.di = (int)((pbit + 32u - c.o) >> 5) - 1;
+    c.w0 = be32(W[c.di]); c.w1 = be32(W[c.di + 1]); c.nxt = be32(W[c.di + 2]);
+}
+__device__ __forceinline__ uint32_t cur_window(const Cursor& c) {
+    return __builtin_amdgcn_alignbit(c.w0, c.w1, 32u - c.o);    // shift taken mod 32: o = 32 -> w1
+}
+__device__ __forceinline__ void cur_advance(Cursor& c, uint32_t nbits) {
+    c.pos += nbits; c.o += nbits;
+    if (c.o > 32u) {
+        c.o -= 32u; c.w0 = c.w1; c.w1 = c.nxt; c.di++;
+        c.nxt = be32(c.W[c.di + 2]);
+    }
+}
+
+struct BlockCtx {          // where in the MCU we are; tables of the current component
+    uint32_t c, z, comp;
+    uint32_t dcb, acb;
+    int acc;               // running DC predictor (write pass) / DC-difference sum (sync pass) of `comp`
+    int a0, a1, a2;        // ... of the three components
+};
+
+__device__ __forceinline__ uint32_t comp_of_block(const JdImg& im, uint32_t c) {
+    const uint32_t nl = im.hs * im.vs;
+    return c < nl ? 0u : c - nl + 1u;
+}
+__device__ __forceinline__ void ctx_load(BlockCtx& k, const JdImg& im) {
+    k.comp = comp_of_block(im, k.c);
+    k.dcb = k.comp == 0 ? im.dc_lut[0] : k.comp == 1 ? im.dc_lut[1] : im.dc_lut[2];
+    k.acb = k.comp == 0 ? im.ac_lut[0] : k.comp == 1 ? im.ac_lut[1] : im.ac_lut[2];
+    k.acc = k.comp == 0 ? k.a0 : k.comp == 1 ? k.a1 : k.a2;
+}
+__device__ __forceinline__ void ctx_store(BlockCtx& k) {
+    if (k.comp == 0) k.a0 = k.acc; else if (k.comp == 1) k.a1 = k.acc; else k.a2 = k.acc;
+}
+
+// Decodes symbols while the next symbol starts before end_bit and blocks remain.
+//   WRITE = true : stores non-zero coefficients (buffer pre-zeroed), reports stream errors in `err`
+//   WRITE = false: speculative (sync pass): invalid codes skip one bit, nothing is stored
+// Restates scanSymbol + decodeBandCoeffecients (main.go:1297-1316, 186-240) with a table lookup in place of
+// the bit-serial canonical search; EXTEND as main.go:196-198 / 234-236.
+template <bool WRITE>
+__device__ __forceinline__ void decode_run(Cursor& cur, const uint16_t* lut, const JdImg& im, BlockCtx& k,
+                                           uint32_t end_bit, uint32_t stream_end, uint32_t& blocks_left,
+                                           int16_t* blk, uint32_t& nslots, uint32_t& err) {
+    while (cur.pos < end_bit && blocks_left != 0) {
+        const uint32_t win = cur_window(cur);
+        const uint32_t tb = k.z ? k.acb : k.dcb;
+        uint32_t e = lut[tb + (win >> (32 - JD_LUT_BITS))];
+        if (e & 0x8000u) e = lut[tb + (e & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)];
+        if (e == 0) {
+            if (WRITE) { err |= JD_ST_HUFF; break; }
+            e = 1;                                   // speculative: step over one bit
+        }
+        const uint32_t total = e & 31u, size = (e >> 5) & 15u, zinc = ((e >> 9) & 63u) + 1u;
+        if (cur.pos + total > stream_end) { if (WRITE) err |= JD_ST_TRUNC; break; }
+        int v = (int)__builtin_amdgcn_ubfe(win, 32u - total, size);
+        const int t = 1 << size;
+        v = (v < (t >> 1)) ? v - t + 1 : v;
+        cur_advance(cur, total);
+        uint32_t zn = k.z + zinc;
+        if (k.z == 0) { k.acc += v; v = k.acc; }
+        if (WRITE) {
+            if (zn > 64u && zinc != 64u) { err |= JD_ST_COEF; break; }
+            if (v != 0 && zn <= 64u) blk[zn - 1] = (int16_t)v;
+        }
+        zn = zn > 64u ? 64u : zn;
+        nslots += zn - k.z;
+        k.z = zn;
+        if (zn == 64u) {
+            ctx_store(k);
+            k.z = 0;
+            k.c = (k.c + 1 == im.bpm) ? 0 : k.c + 1;
+            blocks_left--;
+            blk += 64;
+            ctx_load(k, im);
+        }
+    }
+}
+
+__device__ __forceinline__ void load_lut(uint16_t* lds, const uint16_t* __restrict__ g, uint32_t n) {
+    // n is padded to a multiple of 8 entries by the host
+    const uint4* s = reinterpret_cast<const uint4*>(g);
+    uint4* d = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = threadIdx.x; i < (n >> 3); i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t pack_state(uint32_t rel, uint32_t c, uint32_t z) {
+    rel = rel > 255u ? 255u : rel;
+    return JD_STATE_VALID | rel | (c << 8) | (z << 16);
+}
+
+extern __shared__ __align__(16) uint8_t dyn_lds[];
+
+// ---- restart-interval path: one lane per interval (DC predictors reset, start byte aligned) ----------
+__global__ __launch_bounds__(64) void k1_write_intervals(JdKernelArgs a) {
+    uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    load_lut(lut, a.lut + im.lut_off, im.lut_len);
+    const uint32_t iv = (blockIdx.x - a.prefix[img]) * 64 + threadIdx.x;
+    if (iv >= im.n_intervals) return;
+    const uint32_t slen = a.stream_len[img];
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
+    const uint32_t b0 = a.interval_start[im.interval_base + iv];
+    uint32_t b1 = a.interval_start[im.interval_base + iv + 1];
+    uint32_t err = 0;
+    if (b0 > slen || b1 > slen || b1 < b0) { atomicOr(&a.status[img], JD_ST_RST_COUNT); return; }
+    const uint32_t mcu0 = iv * im.restart_interval;
+    uint32_t nm = im.n_mcus - mcu0; if (nm > im.restart_interval) nm = im.restart_interval;
+    uint32_t blocks_left = nm * im.bpm;
+    Cursor cur; cur_init(cur, W, b0 * 8u);
+    BlockCtx k; k.c = 0; k.z = 0; k.a0 = k.a1 = k.a2 = 0; ctx_load(k, im);
+    uint32_t nslots = 0;
+    int16_t* blk = a.coef + im.coef_off + (uint64_t)mcu0 * im.bpm * 64u;
+    decode_run<true>(cur, lut, im, k, b1 * 8u, b1 * 8u, blocks_left, blk, nslots, err);
+    if (blocks_left != 0 && !err) err |= JD_ST_TRUNC;
+    if (err) atomicOr(&a.status[img], err);
+}
+
+// ---- no-DRI path, pass 1: self-synchronising sub-sequences --------------------------------------------
+// Lane s decodes bits [s*S, (s+1)*S) of the stream starting from a guessed state; then entry states are
+// propagated lane to lane (entry[s] = exit[s-1]) and changed lanes re-decode until nothing changes inside
+// the workgroup.  fixup = 1 re-runs the propagation with lane 0 of each workgroup fed from the previous
+// workgroup's last exit state.
+__device__ __forceinline__ void sync_decode(const JdImg& im, const uint32_t* W, const uint16_t* lut, uint32_t s,
+                                            uint32_t entry, uint32_t sbits, JdSub& rec) {
+    Cursor cur; cur_init(cur, W, s * JD_SUBSEQ_BITS + (entry & 0xFFu));
+    BlockCtx k; k.c = (entry >> 8) & 0xFFu; k.z = (entry >> 16) & 0x7Fu; k.a0 = k.a1 = k.a2 = 0;
+    if (k.c >= im.bpm) k.c = 0;
+    ctx_load(k, im);
+    uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
+    uint32_t bl = 0xFFFFFFFFu, nslots = 0, err = 0;
+    decode_run<false>(cur, lut, im, k, end, sbits, bl, nullptr, nslots, err);
+    ctx_store(k);
+    const uint32_t nxt = (s + 1u) * JD_SUBSEQ_BITS;
+    rec.entry = entry;
+    rec.exit = pack_state(cur.pos > nxt ? cur.pos - nxt : 0u, k.c, k.z);
+    rec.n = nslots; rec.dc[0] = k.a0; rec.dc[1] = k.a1; rec.dc[2] = k.a2;
+}
+
+__global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
+    uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
+    __shared__ uint32_t ex[JD_SYNC_WG];
+    __shared__ uint32_t tmp[8];
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    const uint32_t lw = blockIdx.x - a.prefix[img];
+    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    if (lw * JD_SYNC_WG >= nsub) return;                        // whole workgroup past the stream (uniform)
+    load_lut(lut, a.lut + im.lut_off, im.lut_len);
+    const uint32_t s = lw * JD_SYNC_WG + threadIdx.x;
+    const bool active = s < nsub;
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
+    const uint32_t start_state = pack_state(0, 0, 0);
+    JdSub rec; rec.entry = rec.exit = 0; rec.n = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
+    JdSub* gsub = a.sub + im.subseq_base;
+    if (active) {
+        if (fixup) rec = gsub[s];
+        else sync_decode(im, W, lut, s, start_state, sbits, rec);
+    }
+    const uint32_t exit_before = rec.exit;
+    uint32_t prev_wg_exit = 0;
+    if (threadIdx.x == 0 && s > 0 && fixup) prev_wg_exit = gsub[s - 1].exit;
+    for (int it = 0; it <= JD_SYNC_WG; it++) {
+        ex[threadIdx.x] = rec.exit;
+        __syncthreads();
+        uint32_t ne;
+        if (threadIdx.x > 0) ne = ex[threadIdx.x - 1];
+        else if (s == 0) ne = start_state;
+        else ne = fixup ? prev_wg_exit : rec.entry;
+        const int changed = active && ne != rec.entry;
+        if (!__syncthreads_or(changed)) break;
+        if (changed) sync_decode(im, W, lut, s, ne, sbits, rec);
+    }
+    if (active) gsub[s] = rec;
+    // workgroup totals for the spine scan
+    uint32_t t0, t1, t2, t3;
+    block_excl_scan(active ? rec.n : 0u, tmp, t0);
+    block_excl_scan(active ? (uint32_t)rec.dc[0] : 0u, tmp, t1);
+    block_excl_scan(active ? (uint32_t)rec.dc[1] : 0u, tmp, t2);
+    block_excl_scan(active ? (uint32_t)rec.dc[2] : 0u, tmp, t3);
+    if (threadIdx.x == 0) a.sync_tot[im.sync_wg_base + lw] = make_uint4(t0, t1, t2, t3);
+    const uint32_t last = (nsub - lw * JD_SYNC_WG) < JD_SYNC_WG ? (nsub - lw * JD_SYNC_WG - 1u) : JD_SYNC_WG - 1u;
+    if (fixup && threadIdx.x == last && rec.exit != exit_before) atomicOr(&a.changed[flag_slot], 1u);
+}
+
+// one workgroup per image without DRI: exclusive prefix of the sync workgroup totals
+__global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
+    __shared__ uint32_t tmp[8];
+    const int img = blockIdx.x;
+    const JdImg& im = a.imgs[img];
+    if (im.restart_interval != 0) return;
+    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    uint32_t nwg = (nsub + JD_SYNC_WG - 1u) / JD_SYNC_WG;
+    if (nwg > im.n_sync_wg) nwg = im.n_sync_wg;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    for (uint32_t c0 = 0; c0 < nwg; c0 += 256) {
+        const uint32_t c = c0 + threadIdx.x;
+        uint4 v = c < nwg ? a.sync_tot[im.sync_wg_base + c] : make_uint4(0, 0, 0, 0);
+        uint32_t t0, t1, t2, t3;
+        const uint32_t e0 = block_excl_scan(v.x, tmp, t0), e1 = block_excl_scan(v.y, tmp, t1);
+        const uint32_t e2 = block_excl_scan(v.z, tmp, t2), e3 = block_excl_scan(v.w, tmp, t3);
+        if (c < nwg) a.sync_tot[im.sync_wg_base + c] = make_uint4(r0 + e0, r1 + e1, r2 + e2, r3 + e3);
+        r0 += t0; r1 += t1; r2 += t2; r3 += t3;
+    }
+    // fewer slots than the frame needs = data ended early; surplus (bytes after the last MCU) is ignored,
+    // as the reference stops reading once every MCU is decoded (main.go:769-770)
+    if (threadIdx.x == 0 && r0 < im.n_mcus * im.bpm * 64u) atomicOr(&a.status[img], JD_ST_TRUNC);
+}
+
+// ---- no-DRI path, pass 2: decode each sub-sequence from its exact entry state and store ----------------
+__global__ __launch_bounds__(JD_SYNC_WG) void k1_write_subseq(JdKernelArgs a) {
+    uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
+    __shared__ uint32_t tmp[8];
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    const uint32_t lw = blockIdx.x - a.prefix[img];
+    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    if (lw * JD_SYNC_WG >= nsub) return;
+    load_lut(lut, a.lut + im.lut_off, im.lut_len);
+    const uint32_t s = lw * JD_SYNC_WG + threadIdx.x;
+    const bool active = s < nsub;
+    JdSub rec; rec.entry = 0; rec.n = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
+    if (active) rec = a.sub[im.subseq_base + s];
+    const uint4 base = a.sync_tot[im.sync_wg_base + lw];
+    uint32_t t;
+    const uint32_t slot0 = base.x + block_excl_scan(rec.n, tmp, t);
+    const int p0 = (int)(base.y + block_excl_scan((uint32_t)rec.dc[0], tmp, t));
+    const int p1 = (int)(base.z + block_excl_scan((uint32_t)rec.dc[1], tmp, t));
+    const int p2 = (int)(base.w + block_excl_scan((uint32_t)rec.dc[2], tmp, t));
+    if (!active) return;
+    const uint32_t total_blocks = im.n_mcus * im.bpm;
+    uint32_t err = 0;
+    const uint32_t c = (rec.entry >> 8) & 0xFFu, z = (rec.entry >> 16) & 0x7Fu;
+    const uint32_t blk_idx = slot0 >> 6;
+    if ((slot0 & 63u) != z || (blk_idx % im.bpm) != c) {
+        if (blk_idx < total_blocks) atomicOr(&a.status[img], JD_ST_SYNC);
+        return;
+    }
+    if (blk_idx >= total_blocks) return;                         // trailing pad bits only
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
+    Cursor cur; cur_init(cur, W, s * JD_SUBSEQ_BITS + (rec.entry & 0xFFu));
+    BlockCtx k; k.c = c; k.z = z; k.a0 = p0; k.a1 = p1; k.a2 = p2; ctx_load(k, im);
+    uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
+    uint32_t blocks_left = total_blocks - blk_idx, nslots = 0;
+    int16_t* blk = a.coef + im.coef_off + (uint64_t)blk_idx * 64u;
+    decode_run<true>(cur, lut, im, k, end, sbits, blocks_left, blk, nslots, err);
+    if (err) atomicOr(&a.status[img], err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: dequantise + de-zigzag + IDCT + chroma spread + colour conversion
+// One workgroup = JD_TILE_MCUS consecutive MCUs; wave w handles block-in-MCU w of every MCU (one lane per
+// MCU), so the component -- and with it the quantisation table -- is wave-uniform.  The 8x8 block lives in
+// registers for both 1-D passes (no transpose traffic); samples go back to the block's own LDS slot as
+// int16; then all waves walk the tile's pixels, 4 per thread, and store packed RGB.
+// ------------------------------------------------------------------------------------------------
+struct ZZTables { int n2z[64]; };
+__host__ __device__ constexpr ZZTables make_zz() {
+    ZZTables t{};
+    int r = 0, c = 0;
+    for (int i = 0; i < 64; i++) {
+        t.n2z[r * 8 + c] = i;
+        if (((r + c) & 1) == 0) { if (c == 7) r++; else if (r == 0) c++; else { r--; c++; } }
+        else { if (r == 7) c++; else if (c == 0) r++; else { r++; c--; } }
+    }
+    return t;
+}
+__device__ constexpr ZZTables kZZ = make_zz();     // natural index -> zig-zag index (inverse of zmap.Map1)
+
+// One 1-D pass, main.go:458-528 (columns) / 534-604 (rows): separately rounded fp64 ops, truncating output.
+__device__ __forceinline__ void idct_1d(const JdIdctConst& K, int x0, int x1, int x2, int x3, int x4, int x5, int x6,
+                                        int x7, int (&o)[8]) {
+    const double g0 = (double)x0 * K.S0, g1 = (double)x4 * K.S4, g2 = (double)x2 * K.S2, g3 = (double)x6 * K.S6;
+    const double g4 = (double)x5 * K.S5, g5 = (double)x1 * K.S1, g6 = (double)x7 * K.S7, g7 = (double)x3 * K.S3;
+    const double f4 = g4 - g7, f5 = g5 + g6, f6 = g5 - g6, f7 = g4 + g7;
+    const double e2 = g2 - g3, e3 = g2 + g3, e5 = f5 - f7, e7 = f5 + f7, e8 = f4 + f6;
+    const double d2 = e2 * K.M1, d4 = f4 * K.M2, d5 = e5 * K.M3, d6 = f6 * K.M4, d8 = e8 * K.M5;
+    const double c0 = g0 + g1, c1 = g0 - g1, c2 = d2 - e3, c4 = d4 + d8, c5 = d5 + e7, c6 = d6 - d8;
+    const double c8 = c5 - c6;
+    const double b0 = c0 + e3, b1 = c1 + c2, b2 = c1 - c2, b3 = c0 - e3, b4 = c4 - c8, b6 = c6 - e7;
+    o[0] = (int)(b0 + e7); o[1] = (int)(b1 + b6); o[2] = (int)(b2 + c8); o[3] = (int)(b3 + b4);
+    o[4] = (int)(b3 - b4); o[5] = (int)(b2 - c8); o[6] = (int)(b1 - b6); o[7] = (int)(b0 - e7);
+}
+
+__device__ __forceinline__ int sat16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+
+__device__ __forceinline__ uint32_t rgb_of(int Y, int cb, int cr) {
+    // convertColorSpace, main.go:679-703: float32, constants 1.402/0.344/0.714/1.772, +128 last, clamp, trunc
+    const float y = (float)Y, b = (float)cb, r = (float)cr;
+    float R = __fadd_rn(__fadd_rn(y, __fmul_rn(1.402f, r)), 128.0f);
+    float G = __fadd_rn(__fsub_rn(__fsub_rn(y, __fmul_rn(0.344f, b)), __fmul_rn(0.714f, r)), 128.0f);
+    float B = __fadd_rn(__fadd_rn(y, __fmul_rn(1.772f, b)), 128.0f);
+    R = R < 0.f ? 0.f : R; R = R > 255.f ? 255.f : R;
+    G = G < 0.f ? 0.f : G; G = G > 255.f ? 255.f : G;
+    B = B < 0.f ? 0.f : B; B = B > 255.f ? 255.f : B;
+    return (uint32_t)(int)R | ((uint32_t)(int)G << 8) | ((uint32_t)(int)B << 16);
+}
+
+__global__ __launch_bounds__(384) void k2_idct_colour(JdKernelArgs a, JdIdctConst K) {
+    __shared__ uint2 origin[JD_TILE_MCUS];                        // pixel origin of each MCU of the tile
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    const uint32_t tile = blockIdx.x - a.prefix[img];
+    const uint32_t bpm = im.bpm;
+    const uint32_t MS = bpm * 128u + 16u;                          // LDS bytes per MCU (16 B pad: bank spread)
+    const uint32_t mcu0 = tile * JD_TILE_MCUS;
+    uint32_t nm = im.n_mcus - mcu0; if (nm > JD_TILE_MCUS) nm = JD_TILE_MCUS;
+    const uint32_t nthreads = blockDim.x;
+
+    // ---- stage the tile's coefficients: contiguous in HBM, 16 B per lane --------------------------
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.coef + im.coef_off + (uint64_t)mcu0 * bpm * 64u);
+        const uint32_t per = bpm * 8u, nchunks = nm * per;
+        for (uint32_t kx = threadIdx.x; kx < nchunks; kx += nthreads) {
+            const uint32_t m = kx / per, r = kx - m * per;
+            *reinterpret_cast<uint4*>(dyn_lds + m * MS + r * 16u) = src[kx];
+        }
+        if (threadIdx.x < JD_TILE_MCUS) {
+            const uint32_t M = mcu0 + threadIdx.x;
+            const uint32_t my = M / im.mcux, mx = M - my * im.mcux;
+            origin[threadIdx.x] = make_uint2(mx * 8u * im.hs, my * 8u * im.vs);
+        }
+    }
+    __syncthreads();
+
+    // ---- IDCT: wave = block-in-MCU, lane = MCU -------------------------------------------------------
+    {
+        const uint32_t bidx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t m = threadIdx.x & 63u;
+        if (bidx < bpm && m < nm) {
+            const uint32_t comp = comp_of_block(im, bidx);
+            const uint8_t* __restrict__ q = im.q[comp];
+            uint8_t* slot = dyn_lds + m * MS + bidx * 128u;
+            uint32_t cw[32];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(slot + i * 16);
+                cw[i * 4 + 0] = v.x; cw[i * 4 + 1] = v.y; cw[i * 4 + 2] = v.z; cw[i * 4 + 3] = v.w;
+            }
+            int mid[64];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int x[8], o[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int zi = kZZ.n2z[r * 8 + j];
+                    const int cv = (zi & 1) ? ((int)cw[zi >> 1] >> 16) : (int)(short)(cw[zi >> 1] & 0xFFFFu);
+                    x[r] = cv * (int)q[r * 8 + j];                  // dequantize, main.go:660-662
+                }
+                idct_1d(K, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
+#pragma unroll
+                for (int r = 0; r < 8; r++) mid[r * 8 + j] = o[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int o[8];
+                idct_1d(K, mid[i * 8 + 0], mid[i * 8 + 1], mid[i * 8 + 2], mid[i * 8 + 3], mid[i * 8 + 4], mid[i * 8 + 5],
+                        mid[i * 8 + 6], mid[i * 8 + 7], o);
+                uint4 v;
+                v.x = (uint32_t)(sat16(o[0]) & 0xFFFF) | ((uint32_t)sat16(o[1]) << 16);
+                v.y = (uint32_t)(sat16(o[2]) & 0xFFFF) | ((uint32_t)sat16(o[3]) << 16);
+                v.z = (uint32_t)(sat16(o[4]) & 0xFFFF) | ((uint32_t)sat16(o[5]) << 16);
+                v.w = (uint32_t)(sat16(o[6]) & 0xFFFF) | ((uint32_t)sat16(o[7]) << 16);
+                *reinterpret_cast<uint4*>(slot + i * 16) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- colour: 4 pixels of one row per thread -----------------------------------------------------
+    // spreadCoeffecients (main.go:710-747): chroma sample of pixel (PX,PY) inside the MCU is element
+    // (PY>>1)*8 + (PX>>1) of the MCU's chroma block, whatever the sampling factors.
+    {
+        const uint32_t hs = im.hs, vs = im.vs, nl = hs * vs;
+        const uint32_t gpr = 2u * hs;                              // 4-pixel groups per MCU row
+        const uint32_t rows = 8u * vs;
+        const uint32_t items = rows * JD_TILE_MCUS * gpr;
+        const bool has_chroma = im.ncomp == 3;
+        const bool fast = ((im.row_stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(im.rgb) & 3u) == 0);
+        for (uint32_t it = threadIdx.x; it < items; it += nthreads) {
+            const uint32_t g = it % gpr, t2 = it / gpr;
+            const uint32_t m = t2 % JD_TILE_MCUS, r = t2 / JD_TILE_MCUS;
+            if (m >= nm) continue;
+            const uint2 org = origin[m];
+            const uint32_t X = org.x + g * 4u, Yp = org.y + r;
+            if (Yp >= im.height || X >= im.width) continue;
+            const uint8_t* mb = dyn_lds + m * MS;
+            const uint32_t yblk = (r >> 3) * hs + (g >> 1);
+            const uint2 yv = *reinterpret_cast<const uint2*>(mb + yblk * 128u + (r & 7u) * 16u + (g & 1u) * 8u);
+            uint32_t cbv = 0, crv = 0;
+            if (has_chroma) {
+                const uint32_t co = ((r >> 1) * 8u + g * 2u) * 2u;
+                cbv = *reinterpret_cast<const uint32_t*>(mb + nl * 128u + co);
+                crv = *reinterpret_cast<const uint32_t*>(mb + (nl + 1u) * 128u + co);
+            }
+            const int y0 = (short)(yv.x & 0xFFFF), y1 = (int)yv.x >> 16, y2 = (short)(yv.y & 0xFFFF), y3 = (int)yv.y >> 16;
+            const int cb0 = (short)(cbv & 0xFFFF), cb1 = (int)cbv >> 16, cr0 = (short)(crv & 0xFFFF), cr1 = (int)crv >> 16;
+            const uint32_t p0 = rgb_of(y0, cb0, cr0), p1 = rgb_of(y1, cb0, cr0);
+            const uint32_t p2 = rgb_of(y2, cb1, cr1), p3 = rgb_of(y3, cb1, cr1);
+            uint8_t* dst = im.rgb + (uint64_t)Yp * im.row_stride + X * 3u;
+            if (fast && X + 4u <= im.width) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+                d[0] = p0 | (p1 << 24);
+                d[1] = (p1 >> 8) | (p2 << 16);
+                d[2] = (p2 >> 16) | (p3 << 8);
+            } else {
+                const uint32_t px[4] = { p0, p1, p2, p3 };
+                for (uint32_t j = 0; j < 4 && X + j < im.width; j++) {
+                    dst[j * 3 + 0] = (uint8_t)px[j]; dst[j * 3 + 1] = (uint8_t)(px[j] >> 8); dst[j * 3 + 2] = (uint8_t)(px[j] >> 16);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t wgs, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix_k0;
+    hipLaunchKernelGGL(k0_count, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
+    hipLaunchKernelGGL(k0_spine, dim3(a.n_images), dim3(256), 0, s, x);
+    hipLaunchKernelGGL(k0_scatter, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
+}
+
+void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64), lut_bytes, s, x);
+}
+
+void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
+                     int flag_slot, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    hipLaunchKernelGGL(k1_sync, dim3(wgs), dim3(JD_SYNC_WG), lut_bytes, s, x, fixup, flag_slot);
+}
+
+void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k1_sync_spine, dim3(a.n_images), dim3(256), 0, s, a);
+}
+
+void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    hipLaunchKernelGGL(k1_write_subseq, dim3(wgs), dim3(JD_SYNC_WG), lut_bytes, s, x);
+}
+
+void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t max_bpm,
+                            const JdIdctConst& K, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    const uint32_t lds = JD_TILE_MCUS * (max_bpm * 128u + 16u);
+    hipLaunchKernelGGL(k2_idct_colour, dim3(wgs), dim3(64 * max_bpm), lds, s, x, K);
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+// jd_tables.h -- host-side Huffman LUT packing (see jd_tables.cpp).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "jd_internal.h"
+
+// Appends one packed table (JD_LUT_PRIMARY + 64 * n_secondary entries) to `out`.
+// Returns 0, -1 (counts do not match), -2 (not a prefix code), -3 (too large).
+int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, std::vector<uint16_t>& out);
