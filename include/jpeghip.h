@@ -148,6 +148,11 @@ int jd_batch_coefficients(jd_batch* b, int image, int16_t* coef_out, size_t coef
  * returns, per pipeline stage, the average device time in microseconds measured with hipEvents around
  * that stage's kernels.  names[i] points at static strings.  Returns the number of stages written. */
 int jd_batch_profile(jd_batch* b, int iters, float* stage_us, const char** names, int cap);
+/* The same measurement taken live: after jd_batch_timing(b, 1) every jd_batch_run (up to 64 between reads)
+ * records hipEvents around its stages on the stream it runs on; jd_batch_stage_times synchronises, writes
+ * the per-stage averages in microseconds and returns the number of runs averaged (then starts over). */
+int jd_batch_timing(jd_batch* b, int enable);
+int jd_batch_stage_times(jd_batch* b, float* stage_us, const char** names, int cap);
 /* Bytes of device workspace the batch holds, and per-image facts measured by the last run. */
 size_t jd_batch_workspace_bytes(const jd_batch* b);
 int jd_batch_unstuffed_len(jd_batch* b, int image, size_t* len);

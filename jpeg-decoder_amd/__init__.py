@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "jd_frame_geometry", "jd_decode", "jd_decode_coefficients", "jd_batch_create", "jd_batch_destroy",
     "jd_batch_upload", "jd_batch_upload_unstuffed", "jd_batch_bind_ecs", "jd_batch_bind_rgb", "jd_batch_run",
     "jd_batch_wait", "jd_batch_status", "jd_batch_download", "jd_batch_coefficients", "jd_batch_profile",
-    "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
+    "jd_batch_timing", "jd_batch_stage_times", "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
 ]
 
 
@@ -82,6 +82,8 @@ def _lib():
         L.jd_batch_download.argtypes = [_vp, _ci, _vp, _sz]
         L.jd_batch_coefficients.argtypes = [_vp, _ci, _vp, _sz]
         L.jd_batch_profile.argtypes = [_vp, _ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _ci]
+        L.jd_batch_timing.argtypes = [_vp, _ci]
+        L.jd_batch_stage_times.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _ci]
         L.jd_batch_workspace_bytes.argtypes = [_vp]
         L.jd_batch_workspace_bytes.restype = _sz
         L.jd_batch_unstuffed_len.argtypes = [_vp, _ci, ctypes.POINTER(_sz)]
@@ -247,6 +249,18 @@ class Batch:
         if k < 0:
             raise JpegHipError(k, "jd_batch_profile")
         return {names[i].decode(): float(us[i]) for i in range(k)}
+
+    def timing(self, enable=True):
+        _check(_lib().jd_batch_timing(self._h, 1 if enable else 0), "jd_batch_timing")
+
+    def stage_times(self):
+        """-> (runs averaged, {stage: microseconds}) measured with hipEvents inside the timed runs."""
+        us = (ctypes.c_float * 16)()
+        names = (ctypes.c_char_p * 16)()
+        k = _lib().jd_batch_stage_times(self._h, us, names, 16)
+        if k < 0:
+            raise JpegHipError(k, "jd_batch_stage_times")
+        return k, {names[i].decode(): float(us[i]) for i in range(6)}
 
     def workspace_bytes(self):
         return _lib().jd_batch_workspace_bytes(self._h)

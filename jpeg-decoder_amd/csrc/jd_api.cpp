@@ -173,6 +173,11 @@ struct jd_batch {
     bool dirty = true, ran = false, any_dri = false, any_nodri = false;
     hipStream_t stream = nullptr, last_stream = nullptr;
     JdIdctConst K;
+    // optional per-stage hipEvent timing of jd_batch_run (jd_batch_timing / jd_batch_stage_times)
+    static const int kTimedRuns = 64;
+    std::vector<hipEvent_t> events;           // kTimedRuns x (stages + 1)
+    int timed_runs = 0;
+    bool timing = false;
     static const int kSyncFixups = 2;         // fix-up launches enqueued blindly; more only if the flag says so
 };
 
@@ -387,6 +392,7 @@ extern "C" void jd_batch_destroy(jd_batch* b) {
                      b->d_interval, b->d_changed, b->d_k0, b->d_sub, b->d_sync_tot, b->d_pre_k0, b->d_pre_iv, b->d_pre_sync,
                      b->d_pre_tile };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : b->events) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -453,9 +459,42 @@ extern "C" int jd_batch_run(jd_batch* b, void* hip_stream) {
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
     if (b->dirty) { int rc = refresh(b, s); if (rc) return rc; }
-    for (int st = 0; st < ST_COUNT_; st++) { int rc = enqueue_stage(b, st, s); if (rc) return rc; }
+    const bool timed = b->timing && b->timed_runs < jd_batch::kTimedRuns;
+    hipEvent_t* ev = timed ? &b->events[(size_t)b->timed_runs * (ST_COUNT_ + 1)] : nullptr;
+    if (timed) HIPCHK(hipEventRecord(ev[0], s));
+    for (int st = 0; st < ST_COUNT_; st++) {
+        int rc = enqueue_stage(b, st, s); if (rc) return rc;
+        if (timed) HIPCHK(hipEventRecord(ev[st + 1], s));
+    }
+    if (timed) b->timed_runs++;
     b->last_stream = s; b->ran = true;
     return JD_OK;
+}
+
+extern "C" int jd_batch_timing(jd_batch* b, int enable) {
+    if (!b) return JD_E_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    if (enable && b->events.empty()) {
+        b->events.resize((size_t)jd_batch::kTimedRuns * (ST_COUNT_ + 1));
+        for (auto& e : b->events) HIPCHK(hipEventCreate(&e));
+    }
+    b->timing = enable != 0; b->timed_runs = 0;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_stage_times(jd_batch* b, float* stage_us, const char** names, int cap) {
+    if (!b || !stage_us || cap < ST_COUNT_) return JD_E_ARG;
+    if (b->timed_runs == 0) return JD_E_STATE;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->last_stream));
+    std::vector<double> acc(ST_COUNT_, 0.0);
+    for (int r = 0; r < b->timed_runs; r++) {
+        hipEvent_t* ev = &b->events[(size_t)r * (ST_COUNT_ + 1)];
+        for (int st = 0; st < ST_COUNT_; st++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[st], ev[st + 1])); acc[st] += ms * 1000.0; }
+    }
+    for (int st = 0; st < ST_COUNT_; st++) { stage_us[st] = (float)(acc[st] / b->timed_runs); if (names) names[st] = kStageNames[st]; }
+    const int n = b->timed_runs; b->timed_runs = 0;
+    return n;
 }
 
 extern "C" int jd_batch_wait(jd_batch* b) {
