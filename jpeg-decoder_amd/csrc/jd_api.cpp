@@ -168,6 +168,7 @@ struct jd_batch {
     uint2* d_k0 = nullptr; JdSub* d_sub = nullptr; uint4* d_sync_tot = nullptr;
     uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_tile = nullptr;
     std::vector<uint32_t> pre_k0, pre_iv, pre_sync, pre_tile;
+    std::vector<std::pair<size_t, size_t>> clear_ranges;   // coefficient ranges (int16 offset, count) that need zero-fill
     size_t rgb_own_bytes = 0, stream_bytes = 0, coef_elems = 0, workspace = 0;
     uint32_t max_lut_bytes = 0, max_bpm = 1;
     bool dirty = true, ran = false, any_dri = false, any_nodri = false;
@@ -214,6 +215,17 @@ int refresh(jd_batch* b, hipStream_t s) {
         b->pre_sync[i + 1] = b->pre_sync[i] + nsw;
         b->pre_tile[i + 1] = b->pre_tile[i] + im.n_tiles;
     }
+    // The restart-interval kernel writes whole blocks (zeros included); only the scattered stores of the
+    // sub-sequence path need pre-zeroed coefficients.  Adjacent images merge into one memset.
+    b->clear_ranges.clear();
+    for (int i = 0; i < n; i++) {
+        const JdImg& im = b->img[i];
+        if (im.restart_interval) continue;
+        const size_t cnt = (size_t)im.n_mcus * im.bpm * 64;
+        if (!b->clear_ranges.empty() && b->clear_ranges.back().first + b->clear_ranges.back().second == im.coef_off)
+            b->clear_ranges.back().second += cnt;
+        else b->clear_ranges.emplace_back((size_t)im.coef_off, cnt);
+    }
     const size_t pb = (size_t)(n + 1) * sizeof(uint32_t);
     HIPCHK(hipMemcpyAsync(b->d_img, b->img.data(), (size_t)n * sizeof(JdImg), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_pre_k0, b->pre_k0.data(), pb, hipMemcpyHostToDevice, s));
@@ -236,7 +248,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
     case ST_CLEAR:
         HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)n * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
-        HIPCHK(hipMemsetAsync(b->d_coef, 0, b->coef_elems * sizeof(int16_t), s));
+        for (const auto& r : b->clear_ranges) HIPCHK(hipMemsetAsync(b->d_coef + r.first, 0, r.second * sizeof(int16_t), s));
         break;
     case ST_UNSTUFF:
         jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[n], s);
@@ -518,7 +530,7 @@ extern "C" int jd_batch_wait(jd_batch* b) {
         } while (changed[1] && ++guard < 100000);
         // clear only the sync-related status bits and the coefficients, then re-run the consumers
         HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));
-        HIPCHK(hipMemsetAsync(b->d_coef, 0, b->coef_elems * sizeof(int16_t), s));
+        for (const auto& r : b->clear_ranges) HIPCHK(hipMemsetAsync(b->d_coef + r.first, 0, r.second * sizeof(int16_t), s));
         jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[b->n], s);          // restores K0 status bits (idempotent)
         jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[b->n], b->max_lut_bytes, s);
         jdk_launch_sync_spine(a, s);

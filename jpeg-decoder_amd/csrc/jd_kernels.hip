@@ -40,7 +40,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// exclusive scan over a 256-thread block; `tmp` has >= 8 words of LDS; returns block total in `total`
+// exclusive scan over a thread block (<= 1024); `tmp` has >= 16 words of LDS; returns block total in `total`
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t& total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t inc = wave_incl_scan(v);
@@ -72,8 +72,10 @@ __device__ __forceinline__ void k0_load(const uint8_t* __restrict__ ecs, uint32_
     if (b.n == 16) {
         uint4 v = *reinterpret_cast<const uint4*>(ecs + g0);
         b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
-    } else {
-        for (uint32_t j = 0; j < b.n; j++) b.w[j >> 2] |= (uint32_t)ecs[g0 + j] << ((j & 3) * 8);
+    } else if (b.n) {
+#pragma unroll
+        for (int j = 0; j < 16; j++)                     // static indices: keeps w[] in registers
+            if ((uint32_t)j < b.n) b.w[j >> 2] |= (uint32_t)ecs[g0 + j] << ((j & 3) * 8);
     }
     b.prev = (g0 > 0 && b.n) ? ecs[g0 - 1] : 0;
     b.next = (g0 + 16 < len) ? ecs[g0 + 16] : 0xD9;      // past the segment: behaves like EOI
@@ -88,15 +90,17 @@ __device__ __forceinline__ void k0_classify(const K0Bytes& b, uint32_t& keep, ui
         uint32_t c = k0_byte(b, j);
         uint32_t nx = (j < 15) ? k0_byte(b, j + 1) : b.next;
         if ((uint32_t)j + 1 == b.n) nx = b.next;
-        if ((uint32_t)j < b.n) {
-            if (c == 0xFF) {
-                if (nx == 0x00) keep |= 1u << j;
-            } else if (p == 0xFF) {
-                if (c == 0x00) { /* stuffing */ }
-                else if (c >= 0xD0 && c <= 0xD7) rst |= 1u << j;
-                else bad |= 1u << j;
-            } else keep |= 1u << j;
-        }
+        // branch-free on purpose: hipcc turns an if/else chain that ORs into one of three masks into a
+        // pointer select through scratch memory
+        const uint32_t valid = (uint32_t)j < b.n;
+        const uint32_t isff = c == 0xFF, pff = p == 0xFF;
+        const uint32_t isrst = (c >= 0xD0) & (c <= 0xD7);
+        const uint32_t k = isff ? (uint32_t)(nx == 0x00) : (pff ^ 1u);
+        const uint32_t r = (isff ^ 1u) & pff & isrst;
+        const uint32_t d = (isff ^ 1u) & pff & (uint32_t)(c != 0x00) & (isrst ^ 1u);
+        keep |= (k & valid) << j;
+        rst |= (r & valid) << j;
+        bad |= (d & valid) << j;
         p = c;
     }
 }
@@ -123,13 +127,13 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_count(JdKernelArgs a) {
 }
 
 // one workgroup per image: exclusive prefix over its chunks, stream length, marker count check
-__global__ __launch_bounds__(256) void k0_spine(JdKernelArgs a) {
-    __shared__ uint32_t tmp[8];
+__global__ __launch_bounds__(1024) void k0_spine(JdKernelArgs a) {
+    __shared__ uint32_t tmp[16];
     const int img = blockIdx.x;
     const JdImg& im = a.imgs[img];
     if (im.flags & JD_IMG_UNSTUFFED_INPUT) return;
     uint32_t run_k = 0, run_r = 0;
-    for (uint32_t c0 = 0; c0 < im.n_k0_chunks; c0 += 256) {
+    for (uint32_t c0 = 0; c0 < im.n_k0_chunks; c0 += 1024) {
         const uint32_t c = c0 + threadIdx.x;
         uint2 v = c < im.n_k0_chunks ? a.k0_part[im.k0_chunk_base + c] : make_uint2(0, 0);
         uint32_t tk, tr;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k0_spine(JdKernelArgs a) {
 }
 
 __global__ __launch_bounds__(JD_K0_THREADS) void k0_scatter(JdKernelArgs a) {
-    __shared__ uint32_t tmp[8];
+    __shared__ uint32_t tmp[16];
     __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 16];
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_scatter(JdKernelArgs a) {
     }
     if (rst) {
         uint32_t ridx = base.y + er;                             // markers before this thread
+#pragma unroll
         for (int j = 0; j < 16; j++) {
             if (rst & (1u << j)) {
                 const uint32_t k = ridx + 1;                     // interval that starts after this marker
@@ -198,30 +203,55 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_scatter(JdKernelArgs a) {
 // K1: Huffman decode core
 // ------------------------------------------------------------------------------------------------
 struct Cursor {
-    const uint32_t* W;     // dword 0 of the image's unstuffed data (JD_STREAM_FRONT bytes readable before it)
-    int di;                // dword index held in w0
-    uint32_t w0, w1, nxt;  // big-endian dwords di, di+1, di+2
+    const uint4* Q;        // image stream region as 16-byte quads; quad 0 is the front pad, data starts at quad 1
+    uint32_t qidx, qmax;   // quad held in q; last readable quad of the region
+    uint4 q, qn;           // current quad (raw bytes, shifted down as dwords are consumed) and the next one (prefetched)
+    uint32_t qr;           // dwords left in q
+    uint32_t w0, w1;       // big-endian dwords straddled by the read position
     uint32_t o;            // bits of w0 already consumed, kept in [1,32]
     uint32_t pos;          // absolute bit position
 };
 
 __device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
 
-__device__ __forceinline__ void cur_init(Cursor& c, const uint32_t* W, uint32_t pbit) {
-    c.W = W; c.pos = pbit;
+__device__ __forceinline__ uint32_t cur_take(Cursor& c) {       // next raw dword of the stream
+    const uint32_t v = c.q.x;
+    c.q.x = c.q.y; c.q.y = c.q.z; c.q.z = c.q.w;
+    if (--c.qr == 0) {
+        c.q = c.qn; c.qr = 4; c.qidx++;
+        c.qn = c.Q[c.qidx + 1 < c.qmax ? c.qidx + 1 : c.qmax];  // consumed two quads (~40 symbols) from now
+    }
+    return v;
+}
+__device__ __forceinline__ void cur_init(Cursor& c, const uint8_t* region, uint32_t stream_len, uint32_t pbit) {
+    c.Q = reinterpret_cast<const uint4*>(region);
+    c.pos = pbit;
     c.o = ((pbit - 1u) & 31u) + 1u;
-    c.di = (int)((pbit + 32u - c.o) >> 5) - 1;
-    c.w0 = be32(W[c.di]); c.w1 = be32(W[c.di + 1]); c.nxt = be32(W[c.di + 2]);
+    const uint32_t g = ((pbit + 32u - c.o) >> 5) + 3u;           // dword (front pad included) that becomes w0
+    c.qmax = (JD_STREAM_FRONT + stream_len + JD_STREAM_TAIL) / 16u - 1u;
+    c.qidx = g >> 2; if (c.qidx > c.qmax) c.qidx = c.qmax;
+    c.q = c.Q[c.qidx]; c.qn = c.Q[c.qidx + 1 < c.qmax ? c.qidx + 1 : c.qmax]; c.qr = 4;
+    for (uint32_t k = g & 3u; k; k--) { c.q.x = c.q.y; c.q.y = c.q.z; c.q.z = c.q.w; c.qr--; }
+    c.w0 = be32(cur_take(c));
+    c.w1 = be32(cur_take(c));
 }
 __device__ __forceinline__ uint32_t cur_window(const Cursor& c) {
     return __builtin_amdgcn_alignbit(c.w0, c.w1, 32u - c.o);    // shift taken mod 32: o = 32 -> w1
 }
 __device__ __forceinline__ void cur_advance(Cursor& c, uint32_t nbits) {
     c.pos += nbits; c.o += nbits;
-    if (c.o > 32u) {
-        c.o -= 32u; c.w0 = c.w1; c.w1 = c.nxt; c.di++;
-        c.nxt = be32(c.W[c.di + 2]);
-    }
+    if (c.o > 32u) { c.o -= 32u; c.w0 = c.w1; c.w1 = be32(cur_take(c)); }
+}
+
+struct ImgK {              // per-image constants of the decode loop, read once (wave-uniform)
+    uint32_t bpm, nl, dc0, dc1, dc2, ac0, ac1, ac2;
+};
+__device__ __forceinline__ ImgK load_imgk(const JdImg& im) {
+    ImgK k;
+    k.bpm = im.bpm; k.nl = im.hs * im.vs;
+    k.dc0 = im.dc_lut[0]; k.dc1 = im.dc_lut[1]; k.dc2 = im.dc_lut[2];
+    k.ac0 = im.ac_lut[0]; k.ac1 = im.ac_lut[1]; k.ac2 = im.ac_lut[2];
+    return k;
 }
 
 struct BlockCtx {          // where in the MCU we are; tables of the current component
@@ -235,14 +265,23 @@ __device__ __forceinline__ uint32_t comp_of_block(const JdImg& im, uint32_t c) {
     const uint32_t nl = im.hs * im.vs;
     return c < nl ? 0u : c - nl + 1u;
 }
-__device__ __forceinline__ void ctx_load(BlockCtx& k, const JdImg& im) {
-    k.comp = comp_of_block(im, k.c);
-    k.dcb = k.comp == 0 ? im.dc_lut[0] : k.comp == 1 ? im.dc_lut[1] : im.dc_lut[2];
-    k.acb = k.comp == 0 ? im.ac_lut[0] : k.comp == 1 ? im.ac_lut[1] : im.ac_lut[2];
-    k.acc = k.comp == 0 ? k.a0 : k.comp == 1 ? k.a1 : k.a2;
+// three-way select kept as two v_cndmask: the empty asm stops hipcc from turning the select chain into a
+// dynamically indexed table in scratch memory (scratch traffic shares vmcnt with the coefficient stores)
+__device__ __forceinline__ uint32_t sel3(uint32_t comp, uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t t = comp == 1 ? b : c;
+    asm volatile("" : "+v"(t));
+    return comp == 0 ? a : t;
+}
+__device__ __forceinline__ void ctx_load(BlockCtx& k, const ImgK& ik) {
+    k.comp = k.c < ik.nl ? 0u : k.c - ik.nl + 1u;
+    k.dcb = sel3(k.comp, ik.dc0, ik.dc1, ik.dc2);
+    k.acb = sel3(k.comp, ik.ac0, ik.ac1, ik.ac2);
+    k.acc = (int)sel3(k.comp, (uint32_t)k.a0, (uint32_t)k.a1, (uint32_t)k.a2);
 }
 __device__ __forceinline__ void ctx_store(BlockCtx& k) {
-    if (k.comp == 0) k.a0 = k.acc; else if (k.comp == 1) k.a1 = k.acc; else k.a2 = k.acc;
+    k.a0 = k.comp == 0 ? k.acc : k.a0;
+    k.a1 = k.comp == 1 ? k.acc : k.a1;
+    k.a2 = k.comp >= 2 ? k.acc : k.a2;
 }
 
 // Decodes symbols while the next symbol starts before end_bit and blocks remain.
@@ -251,7 +290,7 @@ __device__ __forceinline__ void ctx_store(BlockCtx& k) {
 // Restates scanSymbol + decodeBandCoeffecients (main.go:1297-1316, 186-240) with a table lookup in place of
 // the bit-serial canonical search; EXTEND as main.go:196-198 / 234-236.
 template <bool WRITE>
-__device__ __forceinline__ void decode_run(Cursor& cur, const uint16_t* lut, const JdImg& im, BlockCtx& k,
+__device__ __forceinline__ void decode_run(Cursor& cur, const uint16_t* lut, const ImgK& im, BlockCtx& k,
                                            uint32_t end_bit, uint32_t stream_end, uint32_t& blocks_left,
                                            int16_t* blk, uint32_t& nslots, uint32_t& err) {
     while (cur.pos < end_bit && blocks_left != 0) {
@@ -304,29 +343,108 @@ __device__ __forceinline__ uint32_t pack_state(uint32_t rel, uint32_t c, uint32_
 
 extern __shared__ __align__(16) uint8_t dyn_lds[];
 
-// ---- restart-interval path: one lane per interval (DC predictors reset, start byte aligned) ----------
-__global__ __launch_bounds__(64) void k1_write_intervals(JdKernelArgs a) {
+// ---- restart-interval path ------------------------------------------------------------------------------
+// One lane per restart interval (DC predictors reset, data byte aligned), one wave per workgroup, and the
+// wave walks its 64 intervals BLOCK-SYNCHRONOUSLY: every lane decodes block b of its interval before any
+// lane starts block b+1.  The block-in-MCU index -- hence component and Huffman tables -- is then
+// wave-uniform, and each lane assembles its block in a private 128-byte LDS slot, so the 64 finished blocks
+// leave as full 128-byte lines (8 lanes x 16 B per block) and zeros never need a separate fill pass.
+#define JD_IV_SLOT 144u      // LDS bytes per lane slot: 128 + 16 pad (spreads equal-z writes over the banks)
+
+__device__ __forceinline__ uint32_t lut_lookup(const uint16_t* lut, uint32_t tb, uint32_t win) {
+    uint32_t e = lut[tb + (win >> (32 - JD_LUT_BITS))];
+    if (e & 0x8000u) e = lut[tb + (e & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)];
+    return e;
+}
+__device__ __forceinline__ int extend_bits(uint32_t win, uint32_t total, uint32_t size) {
+    // EXTEND, main.go:196-198 / 234-236
+    const int v = (int)__builtin_amdgcn_ubfe(win, 32u - total, size);
+    const int t = 1 << size;
+    return (v < (t >> 1)) ? v - t + 1 : v;
+}
+
+__global__ __launch_bounds__(64) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
     uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
+    uint8_t* stage = dyn_lds + lut_bytes;                        // 64 slots of JD_IV_SLOT bytes
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
-    load_lut(lut, a.lut + im.lut_off, im.lut_len);
-    const uint32_t iv = (blockIdx.x - a.prefix[img]) * 64 + threadIdx.x;
-    if (iv >= im.n_intervals) return;
+    const uint32_t lane = threadIdx.x;
+    int16_t* slot = reinterpret_cast<int16_t*>(stage + lane * JD_IV_SLOT);
+#pragma unroll
+    for (int i = 0; i < 9; i++) reinterpret_cast<uint4*>(slot)[i] = make_uint4(0, 0, 0, 0);
+    load_lut(lut, a.lut + im.lut_off, im.lut_len);               // ends with a barrier
+    const ImgK ik = load_imgk(im);
+    const uint32_t ri = im.restart_interval, n_iv = im.n_intervals, n_mcus = im.n_mcus;
+    const uint32_t iv0 = (blockIdx.x - a.prefix[img]) * 64u;
+    const uint32_t iv = iv0 + lane;
+    const bool valid = iv < n_iv;
     const uint32_t slen = a.stream_len[img];
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
-    const uint32_t b0 = a.interval_start[im.interval_base + iv];
-    uint32_t b1 = a.interval_start[im.interval_base + iv + 1];
-    uint32_t err = 0;
-    if (b0 > slen || b1 > slen || b1 < b0) { atomicOr(&a.status[img], JD_ST_RST_COUNT); return; }
-    const uint32_t mcu0 = iv * im.restart_interval;
-    uint32_t nm = im.n_mcus - mcu0; if (nm > im.restart_interval) nm = im.restart_interval;
-    uint32_t blocks_left = nm * im.bpm;
-    Cursor cur; cur_init(cur, W, b0 * 8u);
-    BlockCtx k; k.c = 0; k.z = 0; k.a0 = k.a1 = k.a2 = 0; ctx_load(k, im);
-    uint32_t nslots = 0;
-    int16_t* blk = a.coef + im.coef_off + (uint64_t)mcu0 * im.bpm * 64u;
-    decode_run<true>(cur, lut, im, k, b1 * 8u, b1 * 8u, blocks_left, blk, nslots, err);
-    if (blocks_left != 0 && !err) err |= JD_ST_TRUNC;
+    uint32_t b0 = 0, b1 = 0, err = 0;
+    if (valid) {
+        b0 = a.interval_start[im.interval_base + iv];
+        b1 = a.interval_start[im.interval_base + iv + 1];
+        if (b0 > slen || b1 > slen || b1 < b0) { err = JD_ST_RST_COUNT; b0 = b1 = 0; }
+    }
+    uint32_t nblk = 0;
+    if (valid && !err) { uint32_t nm = n_mcus - iv * ri; nblk = (nm > ri ? ri : nm) * ik.bpm; }
+    const uint32_t nblk_max = ri * ik.bpm;
+    Cursor cur; cur_init(cur, a.stream + im.stream_off, slen, b0 * 8u);
+    int p0 = 0, p1 = 0, p2 = 0;
+    int16_t* const gbase = a.coef + im.coef_off;
+    uint32_t c = 0;
+#pragma unroll 1
+    for (uint32_t b = 0; b < nblk_max; b++) {
+        const uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;                // wave-uniform
+        const uint32_t dcb = comp == 0 ? ik.dc0 : comp == 1 ? ik.dc1 : ik.dc2;
+        const uint32_t acb = comp == 0 ? ik.ac0 : comp == 1 ? ik.ac1 : ik.ac2;
+        uint32_t z = 64;
+        if (b < nblk) {
+            // DC: category, magnitude bits, EXTEND, prediction (main.go:188-201)
+            const uint32_t win = cur_window(cur);
+            uint32_t e = lut_lookup(lut, dcb, win);
+            if (e == 0) { err |= JD_ST_HUFF; e = 1; }
+            const uint32_t total = e & 31u, size = (e >> 5) & 15u;
+            const int diff = extend_bits(win, total, size);
+            cur_advance(cur, total);
+            int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
+            p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
+            slot[0] = (int16_t)pred;
+            z = 1;
+        }
+        // AC: run/size symbols until every lane's block is complete (main.go:204-239)
+        while (__any(z < 64u)) {
+            if (z < 64u) {
+                const uint32_t win = cur_window(cur);
+                uint32_t e = lut_lookup(lut, acb, win);
+                if (e == 0) { err |= JD_ST_HUFF; e = 1; }
+                const uint32_t total = e & 31u, size = (e >> 5) & 15u, zinc = ((e >> 9) & 63u) + 1u;
+                const int v = extend_bits(win, total, size);
+                cur_advance(cur, total);
+                const uint32_t zn = z + zinc;
+                if (zn <= 64u) { if (v != 0) slot[zn - 1] = (int16_t)v; }
+                else if (zinc != 64u) err |= JD_ST_COEF;
+                z = zn;
+            }
+        }
+        __syncthreads();
+        // flush: 8 lanes move one 128-byte block; 8 blocks per pass
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+            const uint32_t t = r * 8u + (lane >> 3), part = lane & 7u;
+            uint4* src = reinterpret_cast<uint4*>(stage + t * JD_IV_SLOT + part * 16u);
+            const uint4 v = *src;
+            *src = make_uint4(0, 0, 0, 0);
+            const uint32_t tiv = iv0 + t;
+            if (tiv < n_iv) {
+                uint32_t nm = n_mcus - tiv * ri; nm = nm > ri ? ri : nm;
+                if (b < nm * ik.bpm)
+                    *reinterpret_cast<uint4*>(gbase + ((uint64_t)tiv * nblk_max + b) * 64u + part * 8u) = v;
+            }
+        }
+        __syncthreads();
+        c = (c + 1u == ik.bpm) ? 0u : c + 1u;
+    }
+    if (nblk && cur.pos > b1 * 8u) err |= JD_ST_TRUNC;            // ran past the interval: data ended early
     if (err) atomicOr(&a.status[img], err);
 }
 
@@ -335,9 +453,9 @@ __global__ __launch_bounds__(64) void k1_write_intervals(JdKernelArgs a) {
 // propagated lane to lane (entry[s] = exit[s-1]) and changed lanes re-decode until nothing changes inside
 // the workgroup.  fixup = 1 re-runs the propagation with lane 0 of each workgroup fed from the previous
 // workgroup's last exit state.
-__device__ __forceinline__ void sync_decode(const JdImg& im, const uint32_t* W, const uint16_t* lut, uint32_t s,
+__device__ __forceinline__ void sync_decode(const ImgK& im, const uint8_t* W, const uint16_t* lut, uint32_t s,
                                             uint32_t entry, uint32_t sbits, JdSub& rec) {
-    Cursor cur; cur_init(cur, W, s * JD_SUBSEQ_BITS + (entry & 0xFFu));
+    Cursor cur; cur_init(cur, W, sbits >> 3, s * JD_SUBSEQ_BITS + (entry & 0xFFu));
     BlockCtx k; k.c = (entry >> 8) & 0xFFu; k.z = (entry >> 16) & 0x7Fu; k.a0 = k.a1 = k.a2 = 0;
     if (k.c >= im.bpm) k.c = 0;
     ctx_load(k, im);
@@ -354,7 +472,7 @@ __device__ __forceinline__ void sync_decode(const JdImg& im, const uint32_t* W, 
 __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
     uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
     __shared__ uint32_t ex[JD_SYNC_WG];
-    __shared__ uint32_t tmp[8];
+    __shared__ uint32_t tmp[16];
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
@@ -364,13 +482,14 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     load_lut(lut, a.lut + im.lut_off, im.lut_len);
     const uint32_t s = lw * JD_SYNC_WG + threadIdx.x;
     const bool active = s < nsub;
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
+    const uint8_t* W = a.stream + im.stream_off;
+    const ImgK ik = load_imgk(im);
     const uint32_t start_state = pack_state(0, 0, 0);
     JdSub rec; rec.entry = rec.exit = 0; rec.n = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
     JdSub* gsub = a.sub + im.subseq_base;
     if (active) {
         if (fixup) rec = gsub[s];
-        else sync_decode(im, W, lut, s, start_state, sbits, rec);
+        else sync_decode(ik, W, lut, s, start_state, sbits, rec);
     }
     const uint32_t exit_before = rec.exit;
     uint32_t prev_wg_exit = 0;
@@ -384,7 +503,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         else ne = fixup ? prev_wg_exit : rec.entry;
         const int changed = active && ne != rec.entry;
         if (!__syncthreads_or(changed)) break;
-        if (changed) sync_decode(im, W, lut, s, ne, sbits, rec);
+        if (changed) sync_decode(ik, W, lut, s, ne, sbits, rec);
     }
     if (active) gsub[s] = rec;
     // workgroup totals for the spine scan
@@ -400,7 +519,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
 
 // one workgroup per image without DRI: exclusive prefix of the sync workgroup totals
 __global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
-    __shared__ uint32_t tmp[8];
+    __shared__ uint32_t tmp[16];
     const int img = blockIdx.x;
     const JdImg& im = a.imgs[img];
     if (im.restart_interval != 0) return;
@@ -426,7 +545,7 @@ __global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
 // ---- no-DRI path, pass 2: decode each sub-sequence from its exact entry state and store ----------------
 __global__ __launch_bounds__(JD_SYNC_WG) void k1_write_subseq(JdKernelArgs a) {
     uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
-    __shared__ uint32_t tmp[8];
+    __shared__ uint32_t tmp[16];
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
@@ -454,13 +573,14 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_write_subseq(JdKernelArgs a) {
         return;
     }
     if (blk_idx >= total_blocks) return;                         // trailing pad bits only
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
-    Cursor cur; cur_init(cur, W, s * JD_SUBSEQ_BITS + (rec.entry & 0xFFu));
-    BlockCtx k; k.c = c; k.z = z; k.a0 = p0; k.a1 = p1; k.a2 = p2; ctx_load(k, im);
+    const uint8_t* W = a.stream + im.stream_off;
+    const ImgK ik = load_imgk(im);
+    Cursor cur; cur_init(cur, W, sbits >> 3, s * JD_SUBSEQ_BITS + (rec.entry & 0xFFu));
+    BlockCtx k; k.c = c; k.z = z; k.a0 = p0; k.a1 = p1; k.a2 = p2; ctx_load(k, ik);
     uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
     uint32_t blocks_left = total_blocks - blk_idx, nslots = 0;
     int16_t* blk = a.coef + im.coef_off + (uint64_t)blk_idx * 64u;
-    decode_run<true>(cur, lut, im, k, end, sbits, blocks_left, blk, nslots, err);
+    decode_run<true>(cur, lut, ik, k, end, sbits, blocks_left, blk, nslots, err);
     if (err) atomicOr(&a.status[img], err);
 }
 
@@ -639,14 +759,15 @@ void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t 
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix_k0;
     hipLaunchKernelGGL(k0_count, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
-    hipLaunchKernelGGL(k0_spine, dim3(a.n_images), dim3(256), 0, s, x);
+    hipLaunchKernelGGL(k0_spine, dim3(a.n_images), dim3(1024), 0, s, x);
     hipLaunchKernelGGL(k0_scatter, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
 }
 
 void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
-    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64), lut_bytes, s, x);
+    const uint32_t lb = (lut_bytes + 15u) & ~15u;
+    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64), lb + 64u * 144u, s, x, lb);
 }
 
 void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
