@@ -343,109 +343,188 @@ __device__ __forceinline__ uint32_t pack_state(uint32_t rel, uint32_t c, uint32_
 
 extern __shared__ __align__(16) uint8_t dyn_lds[];
 
-// ---- restart-interval path ------------------------------------------------------------------------------
-// One lane per restart interval (DC predictors reset, data byte aligned), one wave per workgroup, and the
-// wave walks its 64 intervals BLOCK-SYNCHRONOUSLY: every lane decodes block b of its interval before any
-// lane starts block b+1.  The block-in-MCU index -- hence component and Huffman tables -- is then
-// wave-uniform, and each lane assembles its block in a private 128-byte LDS slot, so the 64 finished blocks
-// leave as full 128-byte lines (8 lanes x 16 B per block) and zeros never need a separate fill pass.
-#define JD_IV_SLOT 144u      // LDS bytes per lane slot: 128 + 16 pad (spreads equal-z writes over the banks)
-
-__device__ __forceinline__ uint32_t lut_lookup(const uint16_t* lut, uint32_t tb, uint32_t win) {
-    uint32_t e = lut[tb + (win >> (32 - JD_LUT_BITS))];
-    if (e & 0x8000u) e = lut[tb + (e & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)];
-    return e;
-}
 __device__ __forceinline__ int extend_bits(uint32_t win, uint32_t total, uint32_t size) {
-    // EXTEND, main.go:196-198 / 234-236
+    // EXTEND, main.go:196-198 / 234-236: v < 2^(size-1)  ->  v - (2^size - 1)
     const int v = (int)__builtin_amdgcn_ubfe(win, 32u - total, size);
-    const int t = 1 << size;
-    return (v < (t >> 1)) ? v - t + 1 : v;
+    const int m = (1 << size) - 1;
+    return (2 * v <= m) ? v - m : v;
 }
 
-__global__ __launch_bounds__(64) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
+// ---- whole-block writer ------------------------------------------------------------------------------------
+// One lane per SEGMENT of the stream: a run of whole blocks whose first bit, first block index and DC
+// predictors are known -- a restart interval (DC predictors reset, data byte aligned), or the blocks that
+// start inside one sub-sequence of the self-synchronising pass.  One wave per workgroup walks its 64
+// segments BLOCK-SYNCHRONOUSLY: every lane finishes block b of its segment before any lane starts b+1.
+//   * each lane assembles its block in a private 128-byte LDS slot, so the 64 finished blocks leave as full
+//     128-byte lines (8 lanes x 16 B per block) and zeros never need a separate fill pass;
+//   * each lane reads the stream through a private LDS ring topped up at the block boundaries with 16-byte
+//     loads issued one block-step ahead, so the symbol loop touches LDS only and never waits on vmcnt
+//     (which the block stores share).
+#define JD_SLOT 144u         // LDS bytes per lane block slot: 128 + 16 pad (spreads equal-z writes over the banks)
+#define JD_RING 144u         // LDS bytes per lane stream ring: 8 quads + 16 pad
+#define JD_RING_DW 32u       // ring capacity in dwords
+
+struct Segment {
+    uint32_t start_bit;      // first bit of the first block
+    uint32_t end_bit;        // decoding past this bit = truncated data
+    uint32_t nblk;           // whole blocks to decode
+    uint32_t blk0;           // index (scan order) of the first block
+    int p0, p1, p2;          // DC predictors at the first block
+};
+
+__device__ __forceinline__ uint4 be32x4(uint4 v) { return make_uint4(be32(v.x), be32(v.y), be32(v.z), be32(v.w)); }
+
+__device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
+                                               const Segment& sg, uint32_t slen, uint32_t err) {
     uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
-    uint8_t* stage = dyn_lds + lut_bytes;                        // 64 slots of JD_IV_SLOT bytes
-    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
-    const JdImg& im = a.imgs[img];
+    uint8_t* slots = dyn_lds + lut_bytes;
+    uint8_t* rings = slots + 64u * JD_SLOT;
+    uint32_t* seg_blk0 = reinterpret_cast<uint32_t*>(rings + 64u * JD_RING);
+    uint32_t* seg_nblk = seg_blk0 + 64;
     const uint32_t lane = threadIdx.x;
-    int16_t* slot = reinterpret_cast<int16_t*>(stage + lane * JD_IV_SLOT);
+    const uint32_t slot_b = lut_bytes + lane * JD_SLOT;          // byte offsets inside dyn_lds
+    const uint32_t ring_b = lut_bytes + 64u * JD_SLOT + lane * JD_RING;
 #pragma unroll
-    for (int i = 0; i < 9; i++) reinterpret_cast<uint4*>(slot)[i] = make_uint4(0, 0, 0, 0);
-    load_lut(lut, a.lut + im.lut_off, im.lut_len);               // ends with a barrier
+    for (int i = 0; i < 9; i++) *reinterpret_cast<uint4*>(dyn_lds + slot_b + i * 16) = make_uint4(0, 0, 0, 0);
+    seg_blk0[lane] = sg.blk0; seg_nblk[lane] = sg.nblk;
     const ImgK ik = load_imgk(im);
-    const uint32_t ri = im.restart_interval, n_iv = im.n_intervals, n_mcus = im.n_mcus;
-    const uint32_t iv0 = (blockIdx.x - a.prefix[img]) * 64u;
-    const uint32_t iv = iv0 + lane;
-    const bool valid = iv < n_iv;
-    const uint32_t slen = a.stream_len[img];
-    uint32_t b0 = 0, b1 = 0, err = 0;
-    if (valid) {
-        b0 = a.interval_start[im.interval_base + iv];
-        b1 = a.interval_start[im.interval_base + iv + 1];
-        if (b0 > slen || b1 > slen || b1 < b0) { err = JD_ST_RST_COUNT; b0 = b1 = 0; }
+    const uint32_t bpm = ik.bpm;
+
+    // ---- prime the ring: three quads, synchronously ----------------------------------------------------
+    const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
+    const uint32_t qmax = (JD_STREAM_FRONT + slen + JD_STREAM_TAIL) / 16u - 1u;
+    const uint32_t o0 = ((sg.start_bit - 1u) & 31u) + 1u;
+    const uint32_t g = ((sg.start_bit + 32u - o0) >> 5) + 3u;    // dword (front pad included) that becomes w0
+    const uint32_t qbase = (g >> 2) < qmax ? (g >> 2) : qmax;
+    {
+        const uint4 v0 = Q[qbase], v1 = Q[qbase + 1 < qmax ? qbase + 1 : qmax], v2 = Q[qbase + 2 < qmax ? qbase + 2 : qmax];
+        *reinterpret_cast<uint4*>(dyn_lds + ring_b) = be32x4(v0);
+        *reinterpret_cast<uint4*>(dyn_lds + ring_b + 16) = be32x4(v1);
+        *reinterpret_cast<uint4*>(dyn_lds + ring_b + 32) = be32x4(v2);
     }
-    uint32_t nblk = 0;
-    if (valid && !err) { uint32_t nm = n_mcus - iv * ri; nblk = (nm > ri ? ri : nm) * ik.bpm; }
-    const uint32_t nblk_max = ri * ik.bpm;
-    Cursor cur; cur_init(cur, a.stream + im.stream_off, slen, b0 * 8u);
-    int p0 = 0, p1 = 0, p2 = 0;
+    uint32_t wq = 3;                                             // quads written to the ring (monotonic)
+    uint32_t rd = g & 3u;                                        // dwords consumed (monotonic, ring index = rd & 31)
+    __syncthreads();
+    const uint32_t* ring = reinterpret_cast<const uint32_t*>(dyn_lds + ring_b);
+    uint32_t w0 = ring[rd & 31u]; rd++;
+    uint32_t w1 = ring[rd & 31u]; rd++;
+    uint32_t nxt = ring[rd & 31u]; rd++;
+    int sh = 32 - (int)o0;                                       // window = alignbit(w0, w1, sh), sh in [0,31]
+    uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;               // quads in flight (requested last boundary)
+    uint32_t npend = 0;
+
+    int p0 = sg.p0, p1 = sg.p1, p2 = sg.p2;
+    uint32_t c = sg.nblk ? sg.blk0 % bpm : 0u;
+    uint32_t emin = 0xFFFFu;                                     // smallest LUT entry seen (0 = invalid code)
     int16_t* const gbase = a.coef + im.coef_off;
-    uint32_t c = 0;
+    uint32_t nmax = sg.nblk;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nmax, d, 64); nmax = t > nmax ? t : nmax; }
+
+    // refill: next dword normally comes from the ring; if the lane outran its ring (a block far larger
+    // than usual) it reads the stream directly until the boundary top-up catches up
+    auto take = [&]() -> uint32_t {
+        uint32_t v;
+        if (rd < wq * 4u) v = ring[rd & 31u];
+        else {
+            uint32_t gi = qbase * 4u + rd; if (gi > qmax * 4u + 3u) gi = qmax * 4u + 3u;
+            v = be32(reinterpret_cast<const uint32_t*>(Q)[gi]);
+        }
+        rd++;
+        return v;
+    };
+
 #pragma unroll 1
-    for (uint32_t b = 0; b < nblk_max; b++) {
-        const uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;                // wave-uniform
-        const uint32_t dcb = comp == 0 ? ik.dc0 : comp == 1 ? ik.dc1 : ik.dc2;
-        const uint32_t acb = comp == 0 ? ik.ac0 : comp == 1 ? ik.ac1 : ik.ac2;
-        uint32_t z = 64;
-        if (b < nblk) {
+    for (uint32_t b = 0; b < nmax; b++) {
+        // ---- ring top-up (commit last boundary's loads, request the next ones) -----------------------
+        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + ring_b + (wq & 7u) * 16u) = be32x4(pq0);
+        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + ring_b + ((wq + 1u) & 7u) * 16u) = be32x4(pq1);
+        wq += npend;
+        if ((rd >> 2) > wq) wq = rd >> 2;                        // outran the ring: skip what was read directly
+        {
+            const uint32_t used = wq - (rd >> 2);                // quads holding unread data (<= 8)
+            const uint32_t freeq = 8u - used;
+            npend = b < sg.nblk ? (freeq < 2u ? freeq : 2u) : 0u;
+            const uint32_t qa = qbase + wq, qb = qbase + wq + 1u;
+            if (npend >= 1) pq0 = Q[qa < qmax ? qa : qmax];
+            if (npend >= 2) pq1 = Q[qb < qmax ? qb : qmax];
+        }
+        // ---- tables of this block's component -----------------------------------------------------------
+        const uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;
+        const uint32_t dcb = sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u;      // byte offsets into the LUT
+        const uint32_t acb = sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
+        uint32_t z = 64, zlast = 63;
+        if (b < sg.nblk) {
             // DC: category, magnitude bits, EXTEND, prediction (main.go:188-201)
-            const uint32_t win = cur_window(cur);
-            uint32_t e = lut_lookup(lut, dcb, win);
-            if (e == 0) { err |= JD_ST_HUFF; e = 1; }
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
+            uint32_t e = *reinterpret_cast<const uint16_t*>(dyn_lds + dcb + (win >> (32 - JD_LUT_BITS)) * 2u);
+            if (e & 0x8000u) e = *reinterpret_cast<const uint16_t*>(dyn_lds + dcb + (e & 0x7FFFu) * 2u + ((win >> (32 - JD_LUT_BITS - 6)) & 63u) * 2u);
+            emin = e < emin ? e : emin;
             const uint32_t total = e & 31u, size = (e >> 5) & 15u;
             const int diff = extend_bits(win, total, size);
-            cur_advance(cur, total);
-            int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
+            sh -= (int)total;
+            if (sh < 0) { sh += 32; w0 = w1; w1 = nxt; nxt = take(); }
+            const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
             p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
-            slot[0] = (int16_t)pred;
+            *reinterpret_cast<int16_t*>(dyn_lds + slot_b) = (int16_t)pred;
             z = 1;
         }
-        // AC: run/size symbols until every lane's block is complete (main.go:204-239)
-        while (__any(z < 64u)) {
-            if (z < 64u) {
-                const uint32_t win = cur_window(cur);
-                uint32_t e = lut_lookup(lut, acb, win);
-                if (e == 0) { err |= JD_ST_HUFF; e = 1; }
-                const uint32_t total = e & 31u, size = (e >> 5) & 15u, zinc = ((e >> 9) & 63u) + 1u;
-                const int v = extend_bits(win, total, size);
-                cur_advance(cur, total);
-                const uint32_t zn = z + zinc;
-                if (zn <= 64u) { if (v != 0) slot[zn - 1] = (int16_t)v; }
-                else if (zinc != 64u) err |= JD_ST_COEF;
-                z = zn;
-            }
+        // ---- AC: run/size symbols until every lane's block is complete (main.go:204-239) ----------------
+        while (z < 64u) {                                         // divergent loop: finished lanes drop out
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
+            uint32_t e = *reinterpret_cast<const uint16_t*>(dyn_lds + acb + (win >> (32 - JD_LUT_BITS)) * 2u);
+            if (e & 0x8000u) e = *reinterpret_cast<const uint16_t*>(dyn_lds + acb + (e & 0x7FFFu) * 2u + ((win >> (32 - JD_LUT_BITS - 6)) & 63u) * 2u);
+            emin = e < emin ? e : emin;
+            const uint32_t total = e & 31u, size = (e >> 5) & 15u;
+            zlast = (e >> 9) & 63u;
+            const int v = extend_bits(win, total, size);
+            sh -= (int)total;
+            if (sh < 0) { sh += 32; w0 = w1; w1 = nxt; nxt = take(); }
+            z += zlast + 1u;
+            if (v != 0 && z <= 64u) *reinterpret_cast<int16_t*>(dyn_lds + slot_b + z * 2u - 2u) = (int16_t)v;
         }
+        if (b < sg.nblk && z > 64u && zlast != 63u) err |= JD_ST_COEF;      // run walked past coefficient 63
         __syncthreads();
-        // flush: 8 lanes move one 128-byte block; 8 blocks per pass
+        // ---- flush: 8 lanes move one 128-byte block; 8 blocks per pass -----------------------------------
 #pragma unroll
         for (uint32_t r = 0; r < 8; r++) {
             const uint32_t t = r * 8u + (lane >> 3), part = lane & 7u;
-            uint4* src = reinterpret_cast<uint4*>(stage + t * JD_IV_SLOT + part * 16u);
+            uint4* src = reinterpret_cast<uint4*>(slots + t * JD_SLOT + part * 16u);
             const uint4 v = *src;
             *src = make_uint4(0, 0, 0, 0);
-            const uint32_t tiv = iv0 + t;
-            if (tiv < n_iv) {
-                uint32_t nm = n_mcus - tiv * ri; nm = nm > ri ? ri : nm;
-                if (b < nm * ik.bpm)
-                    *reinterpret_cast<uint4*>(gbase + ((uint64_t)tiv * nblk_max + b) * 64u + part * 8u) = v;
-            }
+            if (b < seg_nblk[t]) *reinterpret_cast<uint4*>(gbase + ((uint64_t)seg_blk0[t] + b) * 64u + part * 8u) = v;
         }
         __syncthreads();
-        c = (c + 1u == ik.bpm) ? 0u : c + 1u;
+        c = (c + 1u == bpm) ? 0u : c + 1u;
     }
-    if (nblk && cur.pos > b1 * 8u) err |= JD_ST_TRUNC;            // ran past the interval: data ended early
+    if (sg.nblk) {
+        if (emin == 0) err |= JD_ST_HUFF;
+        // bit position = 32 * (dwords consumed before w0) + bits of w0 consumed; w0 is dword (rd - 3)
+        const uint32_t pos = ((qbase * 4u + rd - 3u) - 4u) * 32u + (32u - (uint32_t)sh);
+        if (pos > sg.end_bit) err |= JD_ST_TRUNC;                 // ran past the segment: data ended early
+    }
     if (err) atomicOr(&a.status[img], err);
+}
+
+// ---- restart-interval path: segment = restart interval ------------------------------------------------
+__global__ __launch_bounds__(64) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.lut_off, im.lut_len);
+    const uint32_t ri = im.restart_interval;
+    const uint32_t iv = (blockIdx.x - a.prefix[img]) * 64u + threadIdx.x;
+    const uint32_t slen = a.stream_len[img];
+    Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
+    uint32_t err = 0;
+    if (iv < im.n_intervals) {
+        const uint32_t b0 = a.interval_start[im.interval_base + iv], b1 = a.interval_start[im.interval_base + iv + 1];
+        if (b0 > slen || b1 > slen || b1 < b0) err = JD_ST_RST_COUNT;
+        else {
+            uint32_t nm = im.n_mcus - iv * ri; nm = nm > ri ? ri : nm;
+            sg.start_bit = b0 * 8u; sg.end_bit = b1 * 8u; sg.nblk = nm * im.bpm; sg.blk0 = iv * ri * im.bpm;
+        }
+    }
+    write_segments(a, im, img, lut_bytes, sg, slen, err);
 }
 
 // ---- no-DRI path, pass 1: self-synchronising sub-sequences --------------------------------------------
@@ -767,7 +846,7 @@ void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint3
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 15u) & ~15u;
-    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64), lb + 64u * 144u, s, x, lb);
+    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64), lb + 64u * (144u + 144u) + 512u, s, x, lb);
 }
 
 void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
