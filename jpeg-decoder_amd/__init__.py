@@ -271,6 +271,25 @@ class Batch:
         return v.value
 
 
+def shard_images(n_images, world, rank):
+    """Multi-GPU rule: whole images are independent, so image i goes to rank i % world -- a static
+    round-robin with no data-path collective.  The reference decodes argv[1:] one after another
+    (main.go:1509-1512); this is the same loop dealt over ranks."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank %d / world %d" % (rank, world))
+    return list(range(rank, n_images, world))
+
+
+def max_over_ranks(seconds, dist=None, device=None):
+    """bench.py's timing rule: the job takes as long as its slowest rank."""
+    if dist is None:
+        return float(seconds)
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 # ---- synthetic workload maker (libjdsynth.so; host only) ---------------------------------------------------
 _SYN = None
 
