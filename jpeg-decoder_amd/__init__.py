@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjpeghip.so")
+# JPEGHIP_LIB: experiments only (A/B builds of the same HIP library); the default is the in-tree build
+LIB_PATH = os.environ.get("JPEGHIP_LIB") or os.path.join(_HERE, "libjpeghip.so")
 SYNTH_PATH = os.path.join(_HERE, "libjdsynth.so")
 
 _u8, _u16, _u32 = ctypes.c_uint8, ctypes.c_uint16, ctypes.c_uint32

@@ -698,35 +698,37 @@ __device__ __forceinline__ void idct_1d(const JdIdctConst& K, int x0, int x1, in
     o[4] = (int)(b3 - b4); o[5] = (int)(b2 - c8); o[6] = (int)(b1 - b6); o[7] = (int)(b0 - e7);
 }
 
-__device__ __forceinline__ int sat16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
-
-__device__ __forceinline__ uint32_t rgb_of(int Y, int cb, int cr) {
-    // convertColorSpace, main.go:679-703: float32, constants 1.402/0.344/0.714/1.772, +128 last, clamp, trunc
-    const float y = (float)Y, b = (float)cb, r = (float)cr;
-    float R = __fadd_rn(__fadd_rn(y, __fmul_rn(1.402f, r)), 128.0f);
-    float G = __fadd_rn(__fsub_rn(__fsub_rn(y, __fmul_rn(0.344f, b)), __fmul_rn(0.714f, r)), 128.0f);
-    float B = __fadd_rn(__fadd_rn(y, __fmul_rn(1.772f, b)), 128.0f);
-    R = R < 0.f ? 0.f : R; R = R > 255.f ? 255.f : R;
-    G = G < 0.f ? 0.f : G; G = G > 255.f ? 255.f : G;
-    B = B < 0.f ? 0.f : B; B = B > 255.f ? 255.f : B;
-    return (uint32_t)(int)R | ((uint32_t)(int)G << 8) | ((uint32_t)(int)B << 16);
+// convertColorSpace, main.go:679-703: float32, constants 1.402/0.344/0.714/1.772, +128 last, clamp to
+// [0,255], truncate.  The four chroma products are shared by the pixels that read the same chroma sample.
+// v_cvt_pk_u8_f32 saturates to [0,255] (measured on gfx950: -5.5 -> 0, 300 -> 255, 1e9 -> 255) but rounds to
+// nearest even, so v_floor_f32 goes first: floor(v) is an exact integer, equal to trunc(v) wherever the
+// reference's clamp leaves v alone (v >= 0), and below 0 / above 255 both forms end at 0 / 255.  The result
+// lands in byte `sel` of the packed output dword.
+__device__ __forceinline__ uint32_t put_u8(float v, uint32_t sel, uint32_t old) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(v), sel, old);
 }
 
-__global__ __launch_bounds__(384) void k2_idct_colour(JdKernelArgs a, JdIdctConst K) {
-    __shared__ uint2 origin[JD_TILE_MCUS];                        // pixel origin of each MCU of the tile
-    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
-    const JdImg& im = a.imgs[img];
-    const uint32_t tile = blockIdx.x - a.prefix[img];
-    const uint32_t bpm = im.bpm;
-    const uint32_t MS = bpm * 128u + 16u;                          // LDS bytes per MCU (16 B pad: bank spread)
+// (a variant that kept the column pass's truncated outputs in fp64 -- v_trunc_f64 instead of the
+// i32 round trip -- needs 156 VGPRs and measured 30 % slower on MI355X; the int form stays)
+
+#ifndef JD_K2_ABL
+#define JD_K2_ABL 0          // timing ablations only: 1 = no IDCT arithmetic, 2 = no colour arithmetic
+#endif
+// HS x VS luma blocks + (NC - 1) chroma blocks per MCU; all index arithmetic is compile-time.
+template <int HS, int VS, int NC>
+__device__ __forceinline__ void k2_body(const JdKernelArgs& a, const JdImg& im, uint32_t tile, const JdIdctConst& K,
+                                        uint2* origin) {
+    constexpr uint32_t NL = HS * VS, BPM = NL + NC - 1;
+    constexpr uint32_t MS = BPM * 128u + 16u;                      // LDS bytes per MCU (16 B pad: bank spread)
     const uint32_t mcu0 = tile * JD_TILE_MCUS;
     uint32_t nm = im.n_mcus - mcu0; if (nm > JD_TILE_MCUS) nm = JD_TILE_MCUS;
     const uint32_t nthreads = blockDim.x;
 
     // ---- stage the tile's coefficients: contiguous in HBM, 16 B per lane --------------------------
     {
-        const uint4* src = reinterpret_cast<const uint4*>(a.coef + im.coef_off + (uint64_t)mcu0 * bpm * 64u);
-        const uint32_t per = bpm * 8u, nchunks = nm * per;
+        const uint4* src = reinterpret_cast<const uint4*>(a.coef + im.coef_off + (uint64_t)mcu0 * BPM * 64u);
+        constexpr uint32_t per = BPM * 8u;
+        const uint32_t nchunks = nm * per;
         for (uint32_t kx = threadIdx.x; kx < nchunks; kx += nthreads) {
             const uint32_t m = kx / per, r = kx - m * per;
             *reinterpret_cast<uint4*>(dyn_lds + m * MS + r * 16u) = src[kx];
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(384) void k2_idct_colour(JdKernelArgs a, JdIdctCons
         if (threadIdx.x < JD_TILE_MCUS) {
             const uint32_t M = mcu0 + threadIdx.x;
             const uint32_t my = M / im.mcux, mx = M - my * im.mcux;
-            origin[threadIdx.x] = make_uint2(mx * 8u * im.hs, my * 8u * im.vs);
+            origin[threadIdx.x] = make_uint2(mx * 8u * HS, my * 8u * VS);
         }
     }
     __syncthreads();
@@ -743,8 +745,8 @@ __global__ __launch_bounds__(384) void k2_idct_colour(JdKernelArgs a, JdIdctCons
     {
         const uint32_t bidx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const uint32_t m = threadIdx.x & 63u;
-        if (bidx < bpm && m < nm) {
-            const uint32_t comp = comp_of_block(im, bidx);
+        if (!(JD_K2_ABL & 1) && bidx < BPM && m < nm) {
+            const uint32_t comp = bidx < NL ? 0u : bidx - NL + 1u;
             const uint8_t* __restrict__ q = im.q[comp];
             uint8_t* slot = dyn_lds + m * MS + bidx * 128u;
             uint32_t cw[32];
@@ -756,13 +758,14 @@ __global__ __launch_bounds__(384) void k2_idct_colour(JdKernelArgs a, JdIdctCons
             int mid[64];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                int x[8], o[8];
+                int x[8];
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int zi = kZZ.n2z[r * 8 + j];
                     const int cv = (zi & 1) ? ((int)cw[zi >> 1] >> 16) : (int)(short)(cw[zi >> 1] & 0xFFFFu);
-                    x[r] = cv * (int)q[r * 8 + j];                  // dequantize, main.go:660-662
+                    x[r] = __mul24(cv, (int)q[r * 8 + j]);          // dequantize, main.go:660-662
                 }
+                int o[8];
                 idct_1d(K, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
 #pragma unroll
                 for (int r = 0; r < 8; r++) mid[r * 8 + j] = o[r];
@@ -772,60 +775,92 @@ __global__ __launch_bounds__(384) void k2_idct_colour(JdKernelArgs a, JdIdctCons
                 int o[8];
                 idct_1d(K, mid[i * 8 + 0], mid[i * 8 + 1], mid[i * 8 + 2], mid[i * 8 + 3], mid[i * 8 + 4], mid[i * 8 + 5],
                         mid[i * 8 + 6], mid[i * 8 + 7], o);
-                uint4 v;
-                v.x = (uint32_t)(sat16(o[0]) & 0xFFFF) | ((uint32_t)sat16(o[1]) << 16);
-                v.y = (uint32_t)(sat16(o[2]) & 0xFFFF) | ((uint32_t)sat16(o[3]) << 16);
-                v.z = (uint32_t)(sat16(o[4]) & 0xFFFF) | ((uint32_t)sat16(o[5]) << 16);
-                v.w = (uint32_t)(sat16(o[6]) & 0xFFFF) | ((uint32_t)sat16(o[7]) << 16);
-                *reinterpret_cast<uint4*>(slot + i * 16) = v;
+                // samples are held as saturated int16 (exact for every stream an 8-bit encoder can make)
+                typedef short short2v __attribute__((ext_vector_type(2)));
+                union { short2v s; uint32_t u; } p0, p1, p2, p3;
+                p0.s = __builtin_amdgcn_cvt_pk_i16(o[0], o[1]); p1.s = __builtin_amdgcn_cvt_pk_i16(o[2], o[3]);
+                p2.s = __builtin_amdgcn_cvt_pk_i16(o[4], o[5]); p3.s = __builtin_amdgcn_cvt_pk_i16(o[6], o[7]);
+                *reinterpret_cast<uint4*>(slot + i * 16) = make_uint4(p0.u, p1.u, p2.u, p3.u);
             }
         }
     }
     __syncthreads();
 
-    // ---- colour: 4 pixels of one row per thread -----------------------------------------------------
+    // ---- colour: one row of one luma block (8 pixels, 24 bytes) per thread ---------------------------
     // spreadCoeffecients (main.go:710-747): chroma sample of pixel (PX,PY) inside the MCU is element
     // (PY>>1)*8 + (PX>>1) of the MCU's chroma block, whatever the sampling factors.
     {
-        const uint32_t hs = im.hs, vs = im.vs, nl = hs * vs;
-        const uint32_t gpr = 2u * hs;                              // 4-pixel groups per MCU row
-        const uint32_t rows = 8u * vs;
-        const uint32_t items = rows * JD_TILE_MCUS * gpr;
-        const bool has_chroma = im.ncomp == 3;
-        const bool fast = ((im.row_stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(im.rgb) & 3u) == 0);
-        for (uint32_t it = threadIdx.x; it < items; it += nthreads) {
-            const uint32_t g = it % gpr, t2 = it / gpr;
-            const uint32_t m = t2 % JD_TILE_MCUS, r = t2 / JD_TILE_MCUS;
+        constexpr uint32_t ROWS = 8u * VS, ITEMS = ROWS * JD_TILE_MCUS * HS;
+        const uint32_t rs = im.row_stride;
+        const bool al8 = ((rs & 7u) == 0) && ((reinterpret_cast<uintptr_t>(im.rgb) & 7u) == 0);
+        for (uint32_t it = threadIdx.x; it < ITEMS; it += nthreads) {
+            const uint32_t bx = it % HS, m = (it / HS) % JD_TILE_MCUS, r = it / (HS * JD_TILE_MCUS);
             if (m >= nm) continue;
             const uint2 org = origin[m];
-            const uint32_t X = org.x + g * 4u, Yp = org.y + r;
+            const uint32_t X = org.x + bx * 8u, Yp = org.y + r;
             if (Yp >= im.height || X >= im.width) continue;
             const uint8_t* mb = dyn_lds + m * MS;
-            const uint32_t yblk = (r >> 3) * hs + (g >> 1);
-            const uint2 yv = *reinterpret_cast<const uint2*>(mb + yblk * 128u + (r & 7u) * 16u + (g & 1u) * 8u);
-            uint32_t cbv = 0, crv = 0;
-            if (has_chroma) {
-                const uint32_t co = ((r >> 1) * 8u + g * 2u) * 2u;
-                cbv = *reinterpret_cast<const uint32_t*>(mb + nl * 128u + co);
-                crv = *reinterpret_cast<const uint32_t*>(mb + (nl + 1u) * 128u + co);
+            const uint4 yv = *reinterpret_cast<const uint4*>(mb + ((r >> 3) * HS + bx) * 128u + (r & 7u) * 16u);
+            uint2 cbv = make_uint2(0, 0), crv = make_uint2(0, 0);
+            if (NC == 3) {
+                const uint32_t co = ((r >> 1) * 8u + bx * 4u) * 2u;
+                cbv = *reinterpret_cast<const uint2*>(mb + NL * 128u + co);
+                crv = *reinterpret_cast<const uint2*>(mb + (NL + 1u) * 128u + co);
             }
-            const int y0 = (short)(yv.x & 0xFFFF), y1 = (int)yv.x >> 16, y2 = (short)(yv.y & 0xFFFF), y3 = (int)yv.y >> 16;
-            const int cb0 = (short)(cbv & 0xFFFF), cb1 = (int)cbv >> 16, cr0 = (short)(crv & 0xFFFF), cr1 = (int)crv >> 16;
-            const uint32_t p0 = rgb_of(y0, cb0, cr0), p1 = rgb_of(y1, cb0, cr0);
-            const uint32_t p2 = rgb_of(y2, cb1, cr1), p3 = rgb_of(y3, cb1, cr1);
-            uint8_t* dst = im.rgb + (uint64_t)Yp * im.row_stride + X * 3u;
-            if (fast && X + 4u <= im.width) {
-                uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-                d[0] = p0 | (p1 << 24);
-                d[1] = (p1 >> 8) | (p2 << 16);
-                d[2] = (p2 >> 16) | (p3 << 8);
-            } else {
-                const uint32_t px[4] = { p0, p1, p2, p3 };
-                for (uint32_t j = 0; j < 4 && X + j < im.width; j++) {
-                    dst[j * 3 + 0] = (uint8_t)px[j]; dst[j * 3 + 1] = (uint8_t)(px[j] >> 8); dst[j * 3 + 2] = (uint8_t)(px[j] >> 16);
+            const uint32_t yw[4] = { yv.x, yv.y, yv.z, yv.w };
+            const uint32_t cbw[2] = { cbv.x, cbv.y }, crw[2] = { crv.x, crv.y };
+            uint32_t d[6] = { 0, 0, 0, 0, 0, 0 };
+            if (JD_K2_ABL & 2) { d[0] = yw[0] ^ cbw[0]; d[1] = yw[1] ^ crw[0]; d[2] = yw[2] ^ cbw[1]; d[3] = yw[3] ^ crw[1]; }
+            else
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                           // chroma sample k feeds pixels 2k, 2k+1
+                const int cbi = (k & 1) ? ((int)cbw[k >> 1] >> 16) : (int)(short)(cbw[k >> 1] & 0xFFFFu);
+                const int cri = (k & 1) ? ((int)crw[k >> 1] >> 16) : (int)(short)(crw[k >> 1] & 0xFFFFu);
+                const float cb = (float)cbi, cr = (float)cri;
+                const float rc = __fmul_rn(1.402f, cr), gb = __fmul_rn(0.344f, cb), gr = __fmul_rn(0.714f, cr);
+                const float bc = __fmul_rn(1.772f, cb);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int j = 2 * k + h;
+                    const int yi = h ? ((int)yw[k] >> 16) : (int)(short)(yw[k] & 0xFFFFu);
+                    const float y = (float)yi;
+                    const float R = __fadd_rn(__fadd_rn(y, rc), 128.0f);
+                    const float G = __fadd_rn(__fsub_rn(__fsub_rn(y, gb), gr), 128.0f);
+                    const float B = __fadd_rn(__fadd_rn(y, bc), 128.0f);
+                    d[(3 * j) >> 2] = put_u8(R, (3 * j) & 3, d[(3 * j) >> 2]);
+                    d[(3 * j + 1) >> 2] = put_u8(G, (3 * j + 1) & 3, d[(3 * j + 1) >> 2]);
+                    d[(3 * j + 2) >> 2] = put_u8(B, (3 * j + 2) & 3, d[(3 * j + 2) >> 2]);
                 }
             }
+            uint8_t* dst = im.rgb + (uint64_t)Yp * rs + X * 3u;
+            if (al8 && X + 8u <= im.width) {
+                uint2* o = reinterpret_cast<uint2*>(dst);
+                o[0] = make_uint2(d[0], d[1]); o[1] = make_uint2(d[2], d[3]); o[2] = make_uint2(d[4], d[5]);
+            } else {
+                const uint32_t n = im.width - X < 8u ? im.width - X : 8u;
+#pragma unroll
+                for (uint32_t k = 0; k < 24; k++)
+                    if (k < n * 3u) dst[k] = (uint8_t)(d[k >> 2] >> ((k & 3u) * 8u));
+            }
         }
+    }
+}
+
+#ifndef JD_K2_WPS
+#define JD_K2_WPS 4
+#endif
+__global__ __launch_bounds__(384, JD_K2_WPS) void k2_idct_colour(JdKernelArgs a, JdIdctConst K) {
+    __shared__ uint2 origin[JD_TILE_MCUS];                        // pixel origin of each MCU of the tile
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    const uint32_t tile = blockIdx.x - a.prefix[img];
+    const uint32_t mode = im.ncomp == 1 ? 0u : im.hs + 2u * im.vs - 2u;   // 1: 1x1, 2: 2x1, 3: 1x2, 4: 2x2
+    switch (mode) {                                                // wave-uniform
+    case 0: k2_body<1, 1, 1>(a, im, tile, K, origin); break;
+    case 1: k2_body<1, 1, 3>(a, im, tile, K, origin); break;
+    case 2: k2_body<2, 1, 3>(a, im, tile, K, origin); break;
+    case 3: k2_body<1, 2, 3>(a, im, tile, K, origin); break;
+    default: k2_body<2, 2, 3>(a, im, tile, K, origin); break;
     }
 }
 
