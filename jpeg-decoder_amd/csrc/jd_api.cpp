@@ -211,7 +211,7 @@ int refresh(jd_batch* b, hipStream_t s) {
         const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
         const uint32_t nsw = im.restart_interval ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_WG - 1) / JD_SYNC_WG);
         b->pre_k0[i + 1] = b->pre_k0[i] + im.n_k0_chunks;
-        b->pre_iv[i + 1] = b->pre_iv[i] + (im.restart_interval ? (im.n_intervals + 63) / 64 : 0);
+        b->pre_iv[i + 1] = b->pre_iv[i] + (im.restart_interval ? (im.n_intervals + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES) : 0);
         b->pre_sync[i + 1] = b->pre_sync[i] + nsw;
         b->pre_tile[i + 1] = b->pre_tile[i] + im.n_tiles;
     }
@@ -360,7 +360,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         im.row_stride = (uint32_t)f.width * 3;
         im.ecs_len = 0;
     }
-    if (b->max_lut_bytes > 150 * 1024) { delete b; return JD_E_TABLE; }
+    if (b->max_lut_bytes > 160 * 1024 - JD_W_WAVES * 64 * JD_LANE_LDS - 1024) { delete b; return JD_E_TABLE; }
     b->rgb_own_bytes = rgb_own; b->stream_bytes = stream; b->coef_elems = coef;
 
     size_t tot = 0;

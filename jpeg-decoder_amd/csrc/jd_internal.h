@@ -19,6 +19,11 @@
 #define JD_SUBSEQ_BITS 1024u
 #define JD_SYNC_WG 256
 
+// whole-block Huffman writer: waves per workgroup (they share the lookup tables) and LDS bytes per lane
+// (128-byte block slot + 128-byte stream ring)
+#define JD_W_WAVES 4
+#define JD_LANE_LDS 256u
+
 // unstuff pass: bytes per workgroup
 #define JD_K0_THREADS 256
 #define JD_K0_CHUNK (JD_K0_THREADS * 16)

@@ -297,7 +297,7 @@ __device__ __forceinline__ void decode_run(Cursor& cur, const uint16_t* lut, con
         const uint32_t win = cur_window(cur);
         const uint32_t tb = k.z ? k.acb : k.dcb;
         uint32_t e = lut[tb + (win >> (32 - JD_LUT_BITS))];
-        if (e & 0x8000u) e = lut[tb + (e & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)];
+        if (e & 0x8000u) e = (e & 0x7FFFu) ? lut[tb + (e & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)] : 0u;
         if (e == 0) {
             if (WRITE) { err |= JD_ST_HUFF; break; }
             e = 1;                                   // speculative: step over one bit
@@ -353,16 +353,17 @@ __device__ __forceinline__ int extend_bits(uint32_t win, uint32_t total, uint32_
 // ---- whole-block writer ------------------------------------------------------------------------------------
 // One lane per SEGMENT of the stream: a run of whole blocks whose first bit, first block index and DC
 // predictors are known -- a restart interval (DC predictors reset, data byte aligned), or the blocks that
-// start inside one sub-sequence of the self-synchronising pass.  One wave per workgroup walks its 64
-// segments BLOCK-SYNCHRONOUSLY: every lane finishes block b of its segment before any lane starts b+1.
+// start inside one sub-sequence of the self-synchronising pass.  Each wave walks its 64 segments
+// BLOCK-SYNCHRONOUSLY: every lane finishes block b of its segment before any lane starts b+1.
 //   * each lane assembles its block in a private 128-byte LDS slot, so the 64 finished blocks leave as full
 //     128-byte lines (8 lanes x 16 B per block) and zeros never need a separate fill pass;
-//   * each lane reads the stream through a private LDS ring topped up at the block boundaries with 16-byte
-//     loads issued one block-step ahead, so the symbol loop touches LDS only and never waits on vmcnt
-//     (which the block stores share).
-#define JD_SLOT 144u         // LDS bytes per lane block slot: 128 + 16 pad (spreads equal-z writes over the banks)
-#define JD_RING 144u         // LDS bytes per lane stream ring: 8 quads + 16 pad
-#define JD_RING_DW 32u       // ring capacity in dwords
+//   * each lane reads the stream through a private 128-byte LDS ring topped up at the block boundaries with
+//     16-byte loads issued one block-step ahead; four stream dwords are held in registers and the ring word
+//     that replaces the oldest is requested one refill before it is needed, so the symbol loop's only
+//     dependent LDS access is the table lookup;
+//   * JD_W_WAVES waves share one copy of the lookup tables but are otherwise independent (no workgroup
+//     barrier after the table load): LDS is 256 B per lane + the tables, two workgroups per CU.
+// Slot and ring are swizzled by lane (16-byte chunk index rotated / xor-ed with lane & 7) instead of padded.
 
 struct Segment {
     uint32_t start_bit;      // first bit of the first block
@@ -373,82 +374,121 @@ struct Segment {
 };
 
 __device__ __forceinline__ uint4 be32x4(uint4 v) { return make_uint4(be32(v.x), be32(v.y), be32(v.z), be32(v.w)); }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *reinterpret_cast<const uint16_t*>(dyn_lds + off); }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const uint32_t*>(dyn_lds + off); }
+// LDS operations of one wave execute in order; this only stops the compiler from moving them
+__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
+
+#define JD_E_SKIP ((63u << 9) | 1u)   // stand-in for an invalid code: one bit, ends the block (the error is flagged)
+
+// table lookup: 10-bit primary entry, 64-entry secondary tables for longer codes; 0 (or an escape with offset 0)
+// = no such code
+__device__ __forceinline__ uint32_t lut_lookup(uint32_t tb, uint32_t win, uint32_t& bad) {
+    uint32_t e = lds_u16(tb + ((win >> (32 - JD_LUT_BITS)) << 1));
+    if (__builtin_expect((e & 0x8000u) != 0 || e == 0, 0)) {
+        const uint32_t o = e & 0x7FFFu;
+        e = (e && o) ? lds_u16(tb + (o << 1) + (((win >> (32 - JD_LUT_BITS - 6)) & 63u) << 1)) : 0u;
+        if (e == 0) { bad = 1; e = JD_E_SKIP; }
+    }
+    return e;
+}
 
 __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
                                                const Segment& sg, uint32_t slen, uint32_t err) {
-    uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
-    uint8_t* slots = dyn_lds + lut_bytes;
-    uint8_t* rings = slots + 64u * JD_SLOT;
-    uint32_t* seg_blk0 = reinterpret_cast<uint32_t*>(rings + 64u * JD_RING);
-    uint32_t* seg_nblk = seg_blk0 + 64;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t slot_b = lut_bytes + lane * JD_SLOT;          // byte offsets inside dyn_lds
-    const uint32_t ring_b = lut_bytes + 64u * JD_SLOT + lane * JD_RING;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wbase = lut_bytes + wv * (64u * JD_LANE_LDS);          // lut_bytes: multiple of 128
+    const uint32_t slot_b = wbase + lane * 128u;                         // byte offsets inside dyn_lds
+    const uint32_t ring_b = wbase + 64u * 128u + lane * 128u;
+    const uint32_t rot = (lane & 7u) << 4;
 #pragma unroll
-    for (int i = 0; i < 9; i++) *reinterpret_cast<uint4*>(dyn_lds + slot_b + i * 16) = make_uint4(0, 0, 0, 0);
-    seg_blk0[lane] = sg.blk0; seg_nblk[lane] = sg.nblk;
+    for (int i = 0; i < 8; i++) *reinterpret_cast<uint4*>(dyn_lds + slot_b + i * 16) = make_uint4(0, 0, 0, 0);
     const ImgK ik = load_imgk(im);
     const uint32_t bpm = ik.bpm;
 
-    // ---- prime the ring: three quads, synchronously ----------------------------------------------------
+    // ---- prime the ring: four quads, synchronously -----------------------------------------------------
     const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
     const uint32_t qmax = (JD_STREAM_FRONT + slen + JD_STREAM_TAIL) / 16u - 1u;
     const uint32_t o0 = ((sg.start_bit - 1u) & 31u) + 1u;
-    const uint32_t g = ((sg.start_bit + 32u - o0) >> 5) + 3u;    // dword (front pad included) that becomes w0
+    const uint32_t g = ((sg.start_bit + 32u - o0) >> 5) + 3u;            // dword (front pad included) that becomes w0
     const uint32_t qbase = (g >> 2) < qmax ? (g >> 2) : qmax;
-    {
-        const uint4 v0 = Q[qbase], v1 = Q[qbase + 1 < qmax ? qbase + 1 : qmax], v2 = Q[qbase + 2 < qmax ? qbase + 2 : qmax];
-        *reinterpret_cast<uint4*>(dyn_lds + ring_b) = be32x4(v0);
-        *reinterpret_cast<uint4*>(dyn_lds + ring_b + 16) = be32x4(v1);
-        *reinterpret_cast<uint4*>(dyn_lds + ring_b + 32) = be32x4(v2);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint4 v = Q[qbase + k < qmax ? qbase + k : qmax];
+        *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((k * 16u + rot) & 127u))) = be32x4(v);
     }
-    uint32_t wq = 3;                                             // quads written to the ring (monotonic)
-    uint32_t rd = g & 3u;                                        // dwords consumed (monotonic, ring index = rd & 31)
-    __syncthreads();
-    const uint32_t* ring = reinterpret_cast<const uint32_t*>(dyn_lds + ring_b);
-    uint32_t w0 = ring[rd & 31u]; rd++;
-    uint32_t w1 = ring[rd & 31u]; rd++;
-    uint32_t nxt = ring[rd & 31u]; rd++;
-    int sh = 32 - (int)o0;                                       // window = alignbit(w0, w1, sh), sh in [0,31]
-    uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;               // quads in flight (requested last boundary)
+    // Ring bookkeeping in byte units with the lane's rotation folded in:
+    //   rpb = 4 * (dwords taken from the ring) + rot      wqb = 16 * (quads written to the ring) + rot
+    // (both monotonic; the ring address of a byte index x is ring_b | (x & 127), ring_b being 128-aligned)
+    uint32_t wqb = 64u + rot;
+    uint32_t rpb = (g & 3u) * 4u + rot;
+    wave_lds_order();
+    auto ring_at = [&](uint32_t xb) { return lds_u32(ring_b | (xb & 127u)); };
+    uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 4), nxt = ring_at(rpb + 8);
+    rpb += 12;
+    int sh = 32 - (int)o0;                                               // window = alignbit(w0, w1, sh), sh in [0,31]
+    uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;                       // quads in flight (requested last boundary)
     uint32_t npend = 0;
 
     int p0 = sg.p0, p1 = sg.p1, p2 = sg.p2;
     uint32_t c = sg.nblk ? sg.blk0 % bpm : 0u;
-    uint32_t emin = 0xFFFFu;                                     // smallest LUT entry seen (0 = invalid code)
+    uint32_t bad = 0;
     int16_t* const gbase = a.coef + im.coef_off;
     uint32_t nmax = sg.nblk;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nmax, d, 64); nmax = t > nmax ? t : nmax; }
 
-    // refill: next dword normally comes from the ring; if the lane outran its ring (a block far larger
-    // than usual) it reads the stream directly until the boundary top-up catches up
-    auto take = [&]() -> uint32_t {
-        uint32_t v;
-        if (rd < wq * 4u) v = ring[rd & 31u];
-        else {
-            uint32_t gi = qbase * 4u + rd; if (gi > qmax * 4u + 3u) gi = qmax * 4u + 3u;
-            v = be32(reinterpret_cast<const uint32_t*>(Q)[gi]);
+    // flush plan: in pass r lanes 8t'..8t'+7 move the block of lane t = 8r + (lane >> 3), 16 bytes each
+    const uint32_t part = lane & 7u;
+    uint32_t f_nblk[8];
+    int16_t* f_dst[8];
+#pragma unroll
+    for (uint32_t r = 0; r < 8; r++) {
+        const uint32_t t = r * 8u + (lane >> 3);
+        f_nblk[r] = __shfl(sg.nblk, t, 64);
+        f_dst[r] = gbase + (uint64_t)__shfl(sg.blk0, t, 64) * 64u + part * 8u;
+    }
+    const uint32_t f_src = wbase + (lane >> 3) * 128u + ((part ^ ((lane >> 3) & 7u)) << 4);   // + r * 1024
+
+    auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rot) >> 4); return q < qmax ? q : qmax; };
+    // The ring word that the next refill needs is read at the top of every symbol step, beside the table
+    // lookup (`cand`).  A lane whose read pointer caught up with its write pointer (a block far larger than
+    // the boundary top-ups cover) gets one more quad on the spot; rare, so the test is one wave-wide branch.
+    auto top_up_now = [&]() {
+        if (rpb >= wqb) {
+            if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 127u))) = be32x4(pq0);
+            if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & 127u))) = be32x4(pq1);
+            wqb += npend * 16u; npend = 0;
+            if (rpb >= wqb) {
+                const uint4 v = Q[quad_index(wqb)];
+                *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 127u))) = be32x4(v);
+                wqb += 16u;
+            }
         }
-        rd++;
-        return v;
+        wave_lds_order();
+    };
+    // consume `total` bits; branch-free refill from `cand`
+    auto advance = [&](uint32_t total, uint32_t cand) {
+        sh -= (int)total;
+        const bool r = sh < 0;
+        w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
+        sh += r ? 32 : 0; rpb += r ? 4u : 0u;
     };
 
 #pragma unroll 1
     for (uint32_t b = 0; b < nmax; b++) {
         // ---- ring top-up (commit last boundary's loads, request the next ones) -----------------------
-        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + ring_b + (wq & 7u) * 16u) = be32x4(pq0);
-        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + ring_b + ((wq + 1u) & 7u) * 16u) = be32x4(pq1);
-        wq += npend;
-        if ((rd >> 2) > wq) wq = rd >> 2;                        // outran the ring: skip what was read directly
+        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 127u))) = be32x4(pq0);
+        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & 127u))) = be32x4(pq1);
+        wqb += npend * 16u;
         {
-            const uint32_t used = wq - (rd >> 2);                // quads holding unread data (<= 8)
+            const uint32_t used = (wqb >> 4) - (rpb >> 4);       // quads holding unread data (<= 8); rot < 16 cancels
             const uint32_t freeq = 8u - used;
             npend = b < sg.nblk ? (freeq < 2u ? freeq : 2u) : 0u;
-            const uint32_t qa = qbase + wq, qb = qbase + wq + 1u;
-            if (npend >= 1) pq0 = Q[qa < qmax ? qa : qmax];
-            if (npend >= 2) pq1 = Q[qb < qmax ? qb : qmax];
+            if (npend >= 1) pq0 = Q[quad_index(wqb)];
+            if (npend >= 2) pq1 = Q[quad_index(wqb + 16u)];
         }
+        wave_lds_order();
         // ---- tables of this block's component -----------------------------------------------------------
         const uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;
         const uint32_t dcb = sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u;      // byte offsets into the LUT
@@ -456,63 +496,62 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
         uint32_t z = 64, zlast = 63;
         if (b < sg.nblk) {
             // DC: category, magnitude bits, EXTEND, prediction (main.go:188-201)
+            if (__builtin_amdgcn_ballot_w64(rpb >= wqb)) top_up_now();
+            const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
-            uint32_t e = *reinterpret_cast<const uint16_t*>(dyn_lds + dcb + (win >> (32 - JD_LUT_BITS)) * 2u);
-            if (e & 0x8000u) e = *reinterpret_cast<const uint16_t*>(dyn_lds + dcb + (e & 0x7FFFu) * 2u + ((win >> (32 - JD_LUT_BITS - 6)) & 63u) * 2u);
-            emin = e < emin ? e : emin;
+            const uint32_t e = lut_lookup(dcb, win, bad);
             const uint32_t total = e & 31u, size = (e >> 5) & 15u;
             const int diff = extend_bits(win, total, size);
-            sh -= (int)total;
-            if (sh < 0) { sh += 32; w0 = w1; w1 = nxt; nxt = take(); }
+            advance(total, cand);
             const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
             p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
-            *reinterpret_cast<int16_t*>(dyn_lds + slot_b) = (int16_t)pred;
+            *reinterpret_cast<int16_t*>(dyn_lds + slot_b + rot) = (int16_t)pred;   // coefficient 0: chunk 0 ^ (lane & 7)
             z = 1;
         }
         // ---- AC: run/size symbols until every lane's block is complete (main.go:204-239) ----------------
         while (z < 64u) {                                         // divergent loop: finished lanes drop out
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
+            const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
-            uint32_t e = *reinterpret_cast<const uint16_t*>(dyn_lds + acb + (win >> (32 - JD_LUT_BITS)) * 2u);
-            if (e & 0x8000u) e = *reinterpret_cast<const uint16_t*>(dyn_lds + acb + (e & 0x7FFFu) * 2u + ((win >> (32 - JD_LUT_BITS - 6)) & 63u) * 2u);
-            emin = e < emin ? e : emin;
+            const uint32_t e = lut_lookup(acb, win, bad);
             const uint32_t total = e & 31u, size = (e >> 5) & 15u;
             zlast = (e >> 9) & 63u;
-            const int v = extend_bits(win, total, size);
-            sh -= (int)total;
-            if (sh < 0) { sh += 32; w0 = w1; w1 = nxt; nxt = take(); }
+            advance(total, cand);
             z += zlast + 1u;
-            if (v != 0 && z <= 64u) *reinterpret_cast<int16_t*>(dyn_lds + slot_b + z * 2u - 2u) = (int16_t)v;
+            if (size != 0 && z <= 64u)
+                *reinterpret_cast<int16_t*>(dyn_lds + slot_b + ((z * 2u - 2u) ^ rot)) = (int16_t)extend_bits(win, total, size);
         }
         if (b < sg.nblk && z > 64u && zlast != 63u) err |= JD_ST_COEF;      // run walked past coefficient 63
-        __syncthreads();
+        wave_lds_order();
         // ---- flush: 8 lanes move one 128-byte block; 8 blocks per pass -----------------------------------
 #pragma unroll
         for (uint32_t r = 0; r < 8; r++) {
-            const uint32_t t = r * 8u + (lane >> 3), part = lane & 7u;
-            uint4* src = reinterpret_cast<uint4*>(slots + t * JD_SLOT + part * 16u);
+            uint4* src = reinterpret_cast<uint4*>(dyn_lds + f_src + r * 1024u);
             const uint4 v = *src;
             *src = make_uint4(0, 0, 0, 0);
-            if (b < seg_nblk[t]) *reinterpret_cast<uint4*>(gbase + ((uint64_t)seg_blk0[t] + b) * 64u + part * 8u) = v;
+            if (b < f_nblk[r]) *reinterpret_cast<uint4*>(f_dst[r] + (uint64_t)b * 64u) = v;
         }
-        __syncthreads();
+        wave_lds_order();
         c = (c + 1u == bpm) ? 0u : c + 1u;
     }
     if (sg.nblk) {
-        if (emin == 0) err |= JD_ST_HUFF;
-        // bit position = 32 * (dwords consumed before w0) + bits of w0 consumed; w0 is dword (rd - 3)
-        const uint32_t pos = ((qbase * 4u + rd - 3u) - 4u) * 32u + (32u - (uint32_t)sh);
+        if (bad) err |= JD_ST_HUFF;
+        // bit position = 32 * (dwords consumed before w0) + bits of w0 consumed; w0 is ring dword (rp - 3) and
+        // the front pad holds 4 dwords
+        const uint32_t rp = (rpb - rot) >> 2;
+        const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - (uint32_t)sh);
         if (pos > sg.end_bit) err |= JD_ST_TRUNC;                 // ran past the segment: data ended early
     }
     if (err) atomicOr(&a.status[img], err);
 }
 
 // ---- restart-interval path: segment = restart interval ------------------------------------------------
-__global__ __launch_bounds__(64) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
+__global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.lut_off, im.lut_len);
     const uint32_t ri = im.restart_interval;
-    const uint32_t iv = (blockIdx.x - a.prefix[img]) * 64u + threadIdx.x;
+    const uint32_t iv = (blockIdx.x - a.prefix[img]) * (64u * JD_W_WAVES) + threadIdx.x;
     const uint32_t slen = a.stream_len[img];
     Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
     uint32_t err = 0;
@@ -880,8 +919,11 @@ void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t 
 void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
-    const uint32_t lb = (lut_bytes + 15u) & ~15u;
-    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64), lb + 64u * (144u + 144u) + 512u, s, x, lb);
+    const uint32_t lb = (lut_bytes + 127u) & ~127u;
+    const uint32_t lds = lb + JD_W_WAVES * 64u * JD_LANE_LDS;
+    if (lds > 64u * 1024u)                                       // > 64 KiB of dynamic LDS needs the attribute (per device)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_intervals), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
 void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
