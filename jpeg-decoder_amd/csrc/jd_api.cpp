@@ -215,17 +215,8 @@ int refresh(jd_batch* b, hipStream_t s) {
         b->pre_sync[i + 1] = b->pre_sync[i] + nsw;
         b->pre_tile[i + 1] = b->pre_tile[i] + im.n_tiles;
     }
-    // The restart-interval kernel writes whole blocks (zeros included); only the scattered stores of the
-    // sub-sequence path need pre-zeroed coefficients.  Adjacent images merge into one memset.
+    // Both Huffman writers store whole blocks (zeros included): no coefficient range needs a zero-fill pass.
     b->clear_ranges.clear();
-    for (int i = 0; i < n; i++) {
-        const JdImg& im = b->img[i];
-        if (im.restart_interval) continue;
-        const size_t cnt = (size_t)im.n_mcus * im.bpm * 64;
-        if (!b->clear_ranges.empty() && b->clear_ranges.back().first + b->clear_ranges.back().second == im.coef_off)
-            b->clear_ranges.back().second += cnt;
-        else b->clear_ranges.emplace_back((size_t)im.coef_off, cnt);
-    }
     const size_t pb = (size_t)(n + 1) * sizeof(uint32_t);
     HIPCHK(hipMemcpyAsync(b->d_img, b->img.data(), (size_t)n * sizeof(JdImg), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_pre_k0, b->pre_k0.data(), pb, hipMemcpyHostToDevice, s));

@@ -16,7 +16,7 @@
 #define JD_LUT_SECONDARY 64
 
 // self-synchronising decode: bits per sub-sequence (one lane each)
-#define JD_SUBSEQ_BITS 1024u
+#define JD_SUBSEQ_BITS 4096u
 #define JD_SYNC_WG 256
 
 // whole-block Huffman writer: waves per workgroup (they share the lookup tables) and LDS bytes per lane
@@ -79,8 +79,10 @@ struct JdIdctConst {             // main.go:1339-1354
 struct JdSub {
     uint32_t entry;              // packed entry state used for the last decode of this sub-sequence
     uint32_t exit;               // packed exit state (entry of the next sub-sequence)
-    uint32_t n;                  // coefficient slots advanced
-    int32_t dc[3];               // sum of DC differences per component
+    uint32_t nstart;             // blocks that START inside this sub-sequence
+    uint32_t first;              // bit offset (from the sub-sequence start) of the first of them
+    int32_t dc[3];               // sum of their DC differences, per component
+    uint32_t pad;
 };
 // packed state: [7:0] bit offset past the sub-sequence start, [15:8] block-in-MCU, [23:16] zig-zag index,
 // bit 31 = valid
@@ -98,7 +100,7 @@ struct JdKernelArgs {
     uint32_t* interval_start;
     uint2* k0_part;              // per K0 chunk: (kept bytes, RST markers) -> exclusive prefix after spine
     JdSub* sub;
-    uint4* sync_tot;             // per sync workgroup: (n, dc0, dc1, dc2) totals -> exclusive prefix after spine
+    uint4* sync_tot;             // per sync workgroup: (block starts, dc0, dc1, dc2) totals -> exclusive prefix after spine
     uint32_t* changed;           // sync: set when a workgroup's exit state changed
 };
 

@@ -202,46 +202,7 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_scatter(JdKernelArgs a) {
 // ------------------------------------------------------------------------------------------------
 // K1: Huffman decode core
 // ------------------------------------------------------------------------------------------------
-struct Cursor {
-    const uint4* Q;        // image stream region as 16-byte quads; quad 0 is the front pad, data starts at quad 1
-    uint32_t qidx, qmax;   // quad held in q; last readable quad of the region
-    uint4 q, qn;           // current quad (raw bytes, shifted down as dwords are consumed) and the next one (prefetched)
-    uint32_t qr;           // dwords left in q
-    uint32_t w0, w1;       // big-endian dwords straddled by the read position
-    uint32_t o;            // bits of w0 already consumed, kept in [1,32]
-    uint32_t pos;          // absolute bit position
-};
-
 __device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
-
-__device__ __forceinline__ uint32_t cur_take(Cursor& c) {       // next raw dword of the stream
-    const uint32_t v = c.q.x;
-    c.q.x = c.q.y; c.q.y = c.q.z; c.q.z = c.q.w;
-    if (--c.qr == 0) {
-        c.q = c.qn; c.qr = 4; c.qidx++;
-        c.qn = c.Q[c.qidx + 1 < c.qmax ? c.qidx + 1 : c.qmax];  // consumed two quads (~40 symbols) from now
-    }
-    return v;
-}
-__device__ __forceinline__ void cur_init(Cursor& c, const uint8_t* region, uint32_t stream_len, uint32_t pbit) {
-    c.Q = reinterpret_cast<const uint4*>(region);
-    c.pos = pbit;
-    c.o = ((pbit - 1u) & 31u) + 1u;
-    const uint32_t g = ((pbit + 32u - c.o) >> 5) + 3u;           // dword (front pad included) that becomes w0
-    c.qmax = (JD_STREAM_FRONT + stream_len + JD_STREAM_TAIL) / 16u - 1u;
-    c.qidx = g >> 2; if (c.qidx > c.qmax) c.qidx = c.qmax;
-    c.q = c.Q[c.qidx]; c.qn = c.Q[c.qidx + 1 < c.qmax ? c.qidx + 1 : c.qmax]; c.qr = 4;
-    for (uint32_t k = g & 3u; k; k--) { c.q.x = c.q.y; c.q.y = c.q.z; c.q.z = c.q.w; c.qr--; }
-    c.w0 = be32(cur_take(c));
-    c.w1 = be32(cur_take(c));
-}
-__device__ __forceinline__ uint32_t cur_window(const Cursor& c) {
-    return __builtin_amdgcn_alignbit(c.w0, c.w1, 32u - c.o);    // shift taken mod 32: o = 32 -> w1
-}
-__device__ __forceinline__ void cur_advance(Cursor& c, uint32_t nbits) {
-    c.pos += nbits; c.o += nbits;
-    if (c.o > 32u) { c.o -= 32u; c.w0 = c.w1; c.w1 = be32(cur_take(c)); }
-}
 
 struct ImgK {              // per-image constants of the decode loop, read once (wave-uniform)
     uint32_t bpm, nl, dc0, dc1, dc2, ac0, ac1, ac2;
@@ -254,13 +215,6 @@ __device__ __forceinline__ ImgK load_imgk(const JdImg& im) {
     return k;
 }
 
-struct BlockCtx {          // where in the MCU we are; tables of the current component
-    uint32_t c, z, comp;
-    uint32_t dcb, acb;
-    int acc;               // running DC predictor (write pass) / DC-difference sum (sync pass) of `comp`
-    int a0, a1, a2;        // ... of the three components
-};
-
 __device__ __forceinline__ uint32_t comp_of_block(const JdImg& im, uint32_t c) {
     const uint32_t nl = im.hs * im.vs;
     return c < nl ? 0u : c - nl + 1u;
@@ -272,62 +226,6 @@ __device__ __forceinline__ uint32_t sel3(uint32_t comp, uint32_t a, uint32_t b, 
     asm volatile("" : "+v"(t));
     return comp == 0 ? a : t;
 }
-__device__ __forceinline__ void ctx_load(BlockCtx& k, const ImgK& ik) {
-    k.comp = k.c < ik.nl ? 0u : k.c - ik.nl + 1u;
-    k.dcb = sel3(k.comp, ik.dc0, ik.dc1, ik.dc2);
-    k.acb = sel3(k.comp, ik.ac0, ik.ac1, ik.ac2);
-    k.acc = (int)sel3(k.comp, (uint32_t)k.a0, (uint32_t)k.a1, (uint32_t)k.a2);
-}
-__device__ __forceinline__ void ctx_store(BlockCtx& k) {
-    k.a0 = k.comp == 0 ? k.acc : k.a0;
-    k.a1 = k.comp == 1 ? k.acc : k.a1;
-    k.a2 = k.comp >= 2 ? k.acc : k.a2;
-}
-
-// Decodes symbols while the next symbol starts before end_bit and blocks remain.
-//   WRITE = true : stores non-zero coefficients (buffer pre-zeroed), reports stream errors in `err`
-//   WRITE = false: speculative (sync pass): invalid codes skip one bit, nothing is stored
-// Restates scanSymbol + decodeBandCoeffecients (main.go:1297-1316, 186-240) with a table lookup in place of
-// the bit-serial canonical search; EXTEND as main.go:196-198 / 234-236.
-template <bool WRITE>
-__device__ __forceinline__ void decode_run(Cursor& cur, const uint16_t* lut, const ImgK& im, BlockCtx& k,
-                                           uint32_t end_bit, uint32_t stream_end, uint32_t& blocks_left,
-                                           int16_t* blk, uint32_t& nslots, uint32_t& err) {
-    while (cur.pos < end_bit && blocks_left != 0) {
-        const uint32_t win = cur_window(cur);
-        const uint32_t tb = k.z ? k.acb : k.dcb;
-        uint32_t e = lut[tb + (win >> (32 - JD_LUT_BITS))];
-        if (e & 0x8000u) e = (e & 0x7FFFu) ? lut[tb + (e & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)] : 0u;
-        if (e == 0) {
-            if (WRITE) { err |= JD_ST_HUFF; break; }
-            e = 1;                                   // speculative: step over one bit
-        }
-        const uint32_t total = e & 31u, size = (e >> 5) & 15u, zinc = ((e >> 9) & 63u) + 1u;
-        if (cur.pos + total > stream_end) { if (WRITE) err |= JD_ST_TRUNC; break; }
-        int v = (int)__builtin_amdgcn_ubfe(win, 32u - total, size);
-        const int t = 1 << size;
-        v = (v < (t >> 1)) ? v - t + 1 : v;
-        cur_advance(cur, total);
-        uint32_t zn = k.z + zinc;
-        if (k.z == 0) { k.acc += v; v = k.acc; }
-        if (WRITE) {
-            if (zn > 64u && zinc != 64u) { err |= JD_ST_COEF; break; }
-            if (v != 0 && zn <= 64u) blk[zn - 1] = (int16_t)v;
-        }
-        zn = zn > 64u ? 64u : zn;
-        nslots += zn - k.z;
-        k.z = zn;
-        if (zn == 64u) {
-            ctx_store(k);
-            k.z = 0;
-            k.c = (k.c + 1 == im.bpm) ? 0 : k.c + 1;
-            blocks_left--;
-            blk += 64;
-            ctx_load(k, im);
-        }
-    }
-}
-
 __device__ __forceinline__ void load_lut(uint16_t* lds, const uint16_t* __restrict__ g, uint32_t n) {
     // n is padded to a multiple of 8 entries by the host
     const uint4* s = reinterpret_cast<const uint4*>(g);
@@ -567,48 +465,139 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelAr
 }
 
 // ---- no-DRI path, pass 1: self-synchronising sub-sequences --------------------------------------------
-// Lane s decodes bits [s*S, (s+1)*S) of the stream starting from a guessed state; then entry states are
-// propagated lane to lane (entry[s] = exit[s-1]) and changed lanes re-decode until nothing changes inside
-// the workgroup.  fixup = 1 re-runs the propagation with lane 0 of each workgroup fed from the previous
-// workgroup's last exit state.
-__device__ __forceinline__ void sync_decode(const ImgK& im, const uint8_t* W, const uint16_t* lut, uint32_t s,
-                                            uint32_t entry, uint32_t sbits, JdSub& rec) {
-    Cursor cur; cur_init(cur, W, sbits >> 3, s * JD_SUBSEQ_BITS + (entry & 0xFFu));
-    BlockCtx k; k.c = (entry >> 8) & 0xFFu; k.z = (entry >> 16) & 0x7Fu; k.a0 = k.a1 = k.a2 = 0;
-    if (k.c >= im.bpm) k.c = 0;
-    ctx_load(k, im);
+// Lane s decodes bits [s*S, (s+1)*S) of the stream (S = JD_SUBSEQ_BITS) starting from a guessed state; then
+// entry states are propagated lane to lane (entry[s] = exit[s-1]) and changed lanes re-decode until nothing
+// changes inside the workgroup.  fixup = 1 re-runs the propagation with lane 0 of each workgroup fed from
+// the previous workgroup's last exit state.  (Klein & Wiseman 2003; Weissenberger & Schmidt 2021.)
+//
+// The decode is FREE-RUNNING: every lane walks its own symbols (DC and AC alike) in one loop, so a wave
+// takes as long as its longest sub-sequence, not the sum of per-block maxima.  Each lane reads the stream
+// through a private 32-dword LDS ring laid out [dword][lane] (conflict-free whatever the lanes' positions);
+// when any lane of the wave runs dry, all lanes top their rings up at once, so the global loads come in
+// bursts a couple of hundred symbols apart.  Per sub-sequence it records the exit state, where the first
+// block starts, how many blocks start inside it and the sum of their DC differences per component -- what
+// the spine scan turns into block indices and DC predictors for the write pass (the DC prefix scan).
+#define JD_SPEC_RING_BYTES 8192u      // per wave: 32 dwords x 64 lanes
+static_assert(JD_SYNC_WG == 64 * JD_W_WAVES, "the write pass reuses the sync pass's workgroup prefix");
+
+__device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, uint32_t ring_w, uint32_t lut_b,
+                                            uint32_t s, uint32_t entry, uint32_t sbits, bool run,
+                                            JdSub& rec) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ring_l = ring_w + lane * 4u;                           // ring_w is 8192-aligned
+    auto ring_at = [&](uint32_t xb) { return lds_u32(ring_l | (xb & (JD_SPEC_RING_BYTES - 1u))); };
+    // stream position: bit `start` of the unstuffed stream; data begins at quad 1 (front pad)
+    const uint32_t start = s * JD_SUBSEQ_BITS + (entry & 0xFFu);
     uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
-    uint32_t bl = 0xFFFFFFFFu, nslots = 0, err = 0;
-    decode_run<false>(cur, lut, im, k, end, sbits, bl, nullptr, nslots, err);
-    ctx_store(k);
-    const uint32_t nxt = (s + 1u) * JD_SUBSEQ_BITS;
-    rec.entry = entry;
-    rec.exit = pack_state(cur.pos > nxt ? cur.pos - nxt : 0u, k.c, k.z);
-    rec.n = nslots; rec.dc[0] = k.a0; rec.dc[1] = k.a1; rec.dc[2] = k.a2;
+    const uint32_t o0 = ((start - 1u) & 31u) + 1u;
+    const uint32_t g = ((start + 32u - o0) >> 5) + 3u;                    // dword (front pad included) that becomes w0
+    const uint32_t qbase = (g >> 2) < qmax ? (g >> 2) : qmax;
+    // ring bookkeeping in units of 256 bytes per dword (= the [dword][lane] row pitch)
+    uint32_t rpb = (g & 3u) * 256u, wqb = 0;
+    auto top_up = [&]() {                                                 // every lane fills every free quad
+#pragma unroll 1
+        for (int round = 0; round < 2; round++) {
+            uint4 v[4]; bool take[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t used = (wqb >> 10) - (rpb >> 10);          // quads holding unread dwords
+                take[k] = run && used + (uint32_t)k < 8u;
+                const uint32_t q = qbase + (wqb >> 10) + (uint32_t)k;
+                v[k] = make_uint4(0, 0, 0, 0);
+                if (take[k]) v[k] = Q[q < qmax ? q : qmax];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (take[k]) {
+                    const uint32_t x = wqb + (uint32_t)k * 1024u;
+                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | (x & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].x);
+                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 256u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].y);
+                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 512u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].z);
+                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 768u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].w);
+                }
+            }
+            uint32_t n = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) n += take[k] ? 1u : 0u;
+            wqb += n * 1024u;
+        }
+        wave_lds_order();
+    };
+    top_up();
+    uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 256u), nxt = ring_at(rpb + 512u);
+    rpb += 768u;
+    int sh = 32 - (int)o0;
+    int left = run ? (int)(end - start) : 0;                              // bits of the sub-sequence still to decode
+    uint32_t c = (entry >> 8) & 0xFFu, z = (entry >> 16) & 0x7Fu;
+    if (c >= ik.bpm) c = 0;
+    uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;
+    uint32_t dcb = lut_b + sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u, acb = lut_b + sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
+    uint32_t nstart = 0, first = 0xFFFFFFFFu;
+    int a0 = 0, a1 = 0, a2 = 0;                                          // DC-difference sums per component
+    while (left > 0) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up();
+        const uint32_t cand = ring_at(rpb);
+        const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
+        const uint32_t tb = z ? acb : dcb;
+        uint32_t e = lds_u16(tb + ((win >> (32 - JD_LUT_BITS)) << 1));
+        if (__builtin_expect((e & 0x8000u) != 0 || e == 0, 0)) {
+            const uint32_t o = e & 0x7FFFu;
+            e = (e && o) ? lds_u16(tb + (o << 1) + (((win >> (32 - JD_LUT_BITS - 6)) & 63u) << 1)) : 0u;
+            if (e == 0) e = 1;                                            // speculative: step over one bit
+        }
+        const uint32_t total = e & 31u, size = (e >> 5) & 15u, zinc = ((e >> 9) & 63u) + 1u;
+        if (z == 0) {                                                     // a block starts here: DC difference
+            if (nstart == 0) first = (uint32_t)left;                      // kept as "bits left" at that point
+            nstart++;
+            const int diff = extend_bits(win, total, size);
+            a0 += comp == 0 ? diff : 0; a1 += comp == 1 ? diff : 0; a2 += comp >= 2 ? diff : 0;
+        }
+        sh -= (int)total; left -= (int)total;
+        const bool r = sh < 0;
+        w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
+        sh += r ? 32 : 0; rpb += r ? 256u : 0u;
+        z += zinc;
+        if (z >= 64u) {                                                   // block complete: next block's tables
+            z = 0;
+            c = (c + 1u == ik.bpm) ? 0u : c + 1u;
+            comp = c < ik.nl ? 0u : c - ik.nl + 1u;
+            dcb = lut_b + sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u; acb = lut_b + sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
+        }
+    }
+    wave_lds_order();
+    if (run) {
+        rec.entry = entry;
+        rec.exit = pack_state((uint32_t)(-left), c, z);
+        rec.nstart = nstart;
+        rec.first = nstart ? (end - start) - first + (entry & 0xFFu) : 0u;   // bit offset from the sub-sequence start
+        rec.dc[0] = a0; rec.dc[1] = a1; rec.dc[2] = a2;
+    }
 }
 
+// dyn_lds: [JD_SYNC_WG/64 rings of 8 KiB][lookup tables]
 __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
-    uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
     __shared__ uint32_t ex[JD_SYNC_WG];
     __shared__ uint32_t tmp[16];
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
-    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t slen = a.stream_len[img];
+    const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     if (lw * JD_SYNC_WG >= nsub) return;                        // whole workgroup past the stream (uniform)
-    load_lut(lut, a.lut + im.lut_off, im.lut_len);
+    const uint32_t lut_b = (JD_SYNC_WG / 64u) * JD_SPEC_RING_BYTES;
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + lut_b), a.lut + im.lut_off, im.lut_len);
     const uint32_t s = lw * JD_SYNC_WG + threadIdx.x;
     const bool active = s < nsub;
-    const uint8_t* W = a.stream + im.stream_off;
+    const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
+    const uint32_t qmax = (JD_STREAM_FRONT + slen + JD_STREAM_TAIL) / 16u - 1u;
+    const uint32_t ring_w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * JD_SPEC_RING_BYTES;
     const ImgK ik = load_imgk(im);
     const uint32_t start_state = pack_state(0, 0, 0);
-    JdSub rec; rec.entry = rec.exit = 0; rec.n = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
+    JdSub rec; rec.entry = rec.exit = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0; rec.pad = 0;
     JdSub* gsub = a.sub + im.subseq_base;
-    if (active) {
-        if (fixup) rec = gsub[s];
-        else sync_decode(ik, W, lut, s, start_state, sbits, rec);
-    }
+    if (fixup) { if (active) rec = gsub[s]; }
+    else spec_decode(ik, Q, qmax, ring_w, lut_b, s, start_state, sbits, active, rec);
     const uint32_t exit_before = rec.exit;
     uint32_t prev_wg_exit = 0;
     if (threadIdx.x == 0 && s > 0 && fixup) prev_wg_exit = gsub[s - 1].exit;
@@ -619,14 +608,15 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         if (threadIdx.x > 0) ne = ex[threadIdx.x - 1];
         else if (s == 0) ne = start_state;
         else ne = fixup ? prev_wg_exit : rec.entry;
-        const int changed = active && ne != rec.entry;
+        const bool changed = active && ne != rec.entry;
         if (!__syncthreads_or(changed)) break;
-        if (changed) sync_decode(ik, W, lut, s, ne, sbits, rec);
+        if (__builtin_amdgcn_ballot_w64(changed))                // wave-uniform: skip waves with nothing to redo
+            spec_decode(ik, Q, qmax, ring_w, lut_b, s, ne, sbits, changed, rec);
     }
     if (active) gsub[s] = rec;
     // workgroup totals for the spine scan
     uint32_t t0, t1, t2, t3;
-    block_excl_scan(active ? rec.n : 0u, tmp, t0);
+    block_excl_scan(active ? rec.nstart : 0u, tmp, t0);
     block_excl_scan(active ? (uint32_t)rec.dc[0] : 0u, tmp, t1);
     block_excl_scan(active ? (uint32_t)rec.dc[1] : 0u, tmp, t2);
     block_excl_scan(active ? (uint32_t)rec.dc[2] : 0u, tmp, t3);
@@ -655,51 +645,46 @@ __global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
         if (c < nwg) a.sync_tot[im.sync_wg_base + c] = make_uint4(r0 + e0, r1 + e1, r2 + e2, r3 + e3);
         r0 += t0; r1 += t1; r2 += t2; r3 += t3;
     }
-    // fewer slots than the frame needs = data ended early; surplus (bytes after the last MCU) is ignored,
-    // as the reference stops reading once every MCU is decoded (main.go:769-770)
-    if (threadIdx.x == 0 && r0 < im.n_mcus * im.bpm * 64u) atomicOr(&a.status[img], JD_ST_TRUNC);
+    // fewer block starts than the frame has blocks = data ended early; surplus (bits after the last MCU) is
+    // ignored, as the reference stops reading once every MCU is decoded (main.go:769-770)
+    if (threadIdx.x == 0 && r0 < im.n_mcus * im.bpm) atomicOr(&a.status[img], JD_ST_TRUNC);
 }
 
-// ---- no-DRI path, pass 2: decode each sub-sequence from its exact entry state and store ----------------
-__global__ __launch_bounds__(JD_SYNC_WG) void k1_write_subseq(JdKernelArgs a) {
-    uint16_t* lut = reinterpret_cast<uint16_t*>(dyn_lds);
+// ---- no-DRI path, pass 2: segment = the blocks that start inside one sub-sequence ------------------------
+__global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs a, uint32_t lut_bytes) {
     __shared__ uint32_t tmp[16];
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
-    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t slen = a.stream_len[img];
+    const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     if (lw * JD_SYNC_WG >= nsub) return;
-    load_lut(lut, a.lut + im.lut_off, im.lut_len);
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.lut_off, im.lut_len);
     const uint32_t s = lw * JD_SYNC_WG + threadIdx.x;
     const bool active = s < nsub;
-    JdSub rec; rec.entry = 0; rec.n = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
+    JdSub rec; rec.entry = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
     if (active) rec = a.sub[im.subseq_base + s];
     const uint4 base = a.sync_tot[im.sync_wg_base + lw];
     uint32_t t;
-    const uint32_t slot0 = base.x + block_excl_scan(rec.n, tmp, t);
-    const int p0 = (int)(base.y + block_excl_scan((uint32_t)rec.dc[0], tmp, t));
-    const int p1 = (int)(base.z + block_excl_scan((uint32_t)rec.dc[1], tmp, t));
-    const int p2 = (int)(base.w + block_excl_scan((uint32_t)rec.dc[2], tmp, t));
-    if (!active) return;
+    const uint32_t blk0 = base.x + block_excl_scan(rec.nstart, tmp, t);
+    Segment sg;
+    sg.p0 = (int)(base.y + block_excl_scan((uint32_t)rec.dc[0], tmp, t));
+    sg.p1 = (int)(base.z + block_excl_scan((uint32_t)rec.dc[1], tmp, t));
+    sg.p2 = (int)(base.w + block_excl_scan((uint32_t)rec.dc[2], tmp, t));
     const uint32_t total_blocks = im.n_mcus * im.bpm;
     uint32_t err = 0;
-    const uint32_t c = (rec.entry >> 8) & 0xFFu, z = (rec.entry >> 16) & 0x7Fu;
-    const uint32_t blk_idx = slot0 >> 6;
-    if ((slot0 & 63u) != z || (blk_idx % im.bpm) != c) {
-        if (blk_idx < total_blocks) atomicOr(&a.status[img], JD_ST_SYNC);
-        return;
+    sg.start_bit = s * JD_SUBSEQ_BITS + rec.first; sg.end_bit = sbits; sg.blk0 = blk0;
+    sg.nblk = blk0 < total_blocks ? (rec.nstart < total_blocks - blk0 ? rec.nstart : total_blocks - blk0) : 0u;
+    if (sg.nblk) {
+        // consistency of the scan with the sub-sequence's own state: the first block that starts here must be
+        // the block-in-MCU the entry state implies
+        const uint32_t c = (rec.entry >> 8) & 0xFFu, z = (rec.entry >> 16) & 0x7Fu;
+        const uint32_t cf = z == 0 ? c : (c + 1u == im.bpm ? 0u : c + 1u);
+        if (blk0 % im.bpm != cf) { err = JD_ST_SYNC; sg.nblk = 0; }
     }
-    if (blk_idx >= total_blocks) return;                         // trailing pad bits only
-    const uint8_t* W = a.stream + im.stream_off;
-    const ImgK ik = load_imgk(im);
-    Cursor cur; cur_init(cur, W, sbits >> 3, s * JD_SUBSEQ_BITS + (rec.entry & 0xFFu));
-    BlockCtx k; k.c = c; k.z = z; k.a0 = p0; k.a1 = p1; k.a2 = p2; ctx_load(k, ik);
-    uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
-    uint32_t blocks_left = total_blocks - blk_idx, nslots = 0;
-    int16_t* blk = a.coef + im.coef_off + (uint64_t)blk_idx * 64u;
-    decode_run<true>(cur, lut, ik, k, end, sbits, blocks_left, blk, nslots, err);
-    if (err) atomicOr(&a.status[img], err);
+    if (!sg.nblk) { sg.start_bit = 0; sg.blk0 = 0; }
+    write_segments(a, im, img, lut_bytes, sg, slen, err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -922,7 +907,7 @@ void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint3
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
     const uint32_t lds = lb + JD_W_WAVES * 64u * JD_LANE_LDS;
     if (lds > 64u * 1024u)                                       // > 64 KiB of dynamic LDS needs the attribute (per device)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_intervals), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_intervals), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
@@ -930,7 +915,9 @@ void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t w
                      int flag_slot, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
-    hipLaunchKernelGGL(k1_sync, dim3(wgs), dim3(JD_SYNC_WG), lut_bytes, s, x, fixup, flag_slot);
+    const uint32_t lb = (lut_bytes + 15u) & ~15u;
+    const uint32_t lds = (JD_SYNC_WG / 64u) * JD_SPEC_RING_BYTES + lb;
+    hipLaunchKernelGGL(k1_sync, dim3(wgs), dim3(JD_SYNC_WG), lds, s, x, fixup, flag_slot);
 }
 
 void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s) {
@@ -940,7 +927,11 @@ void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s) {
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
-    hipLaunchKernelGGL(k1_write_subseq, dim3(wgs), dim3(JD_SYNC_WG), lut_bytes, s, x);
+    const uint32_t lb = (lut_bytes + 127u) & ~127u;
+    const uint32_t lds = lb + JD_W_WAVES * 64u * JD_LANE_LDS;
+    if (lds > 64u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_subseq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k1_write_subseq, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t max_bpm,
