@@ -209,7 +209,7 @@ int refresh(jd_batch* b, hipStream_t s) {
         const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
         im.n_k0_chunks = stuffed ? (uint32_t)((im.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK) : 0;
         const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
-        const uint32_t nsw = im.restart_interval ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_WG - 1) / JD_SYNC_WG);
+        const uint32_t nsw = im.restart_interval ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_OWN - 1) / JD_SYNC_OWN);
         b->pre_k0[i + 1] = b->pre_k0[i] + im.n_k0_chunks;
         b->pre_iv[i + 1] = b->pre_iv[i] + (im.restart_interval ? (im.n_intervals + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES) : 0);
         b->pre_sync[i + 1] = b->pre_sync[i] + nsw;
@@ -344,8 +344,8 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         im.k0_chunk_base = k0c; k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);
         im.interval_base = ivb; ivb += im.n_intervals + 1;
         im.n_subseq_cap = (uint32_t)(((uint64_t)ecs_cap[i] * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
-        im.n_sync_wg = f.restart_interval ? 0 : (im.n_subseq_cap + JD_SYNC_WG - 1) / JD_SYNC_WG;
-        im.subseq_base = subb; subb += f.restart_interval ? 0 : im.n_sync_wg * JD_SYNC_WG;
+        im.n_sync_wg = f.restart_interval ? 0 : (im.n_subseq_cap + JD_SYNC_OWN - 1) / JD_SYNC_OWN;
+        im.subseq_base = subb; subb += f.restart_interval ? 0 : im.n_sync_wg * JD_SYNC_OWN;
         im.sync_wg_base = swb; swb += im.n_sync_wg;
         im.n_tiles = (im.n_mcus + JD_TILE_MCUS - 1) / JD_TILE_MCUS; im.tile_base = tileb; tileb += im.n_tiles;
         im.row_stride = (uint32_t)f.width * 3;

@@ -477,15 +477,24 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelAr
 // bursts a couple of hundred symbols apart.  Per sub-sequence it records the exit state, where the first
 // block starts, how many blocks start inside it and the sum of their DC differences per component -- what
 // the spine scan turns into block indices and DC predictors for the write pass (the DC prefix scan).
-#define JD_SPEC_RING_BYTES 8192u      // per wave: 32 dwords x 64 lanes
+#define JD_SPEC_RING_DW 16u                                   // ring depth in dwords (4 quads)
+#define JD_SPEC_RING_BYTES (JD_SPEC_RING_DW * 256u)           // per wave: [dword][lane]
 static_assert(JD_SYNC_WG == 64 * JD_W_WAVES, "the write pass reuses the sync pass's workgroup prefix");
 
-__device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, uint32_t ring_w, uint32_t lut_b,
-                                            uint32_t s, uint32_t entry, uint32_t sbits, bool run,
-                                            JdSub& rec) {
+// LDS map of k1_sync (byte offsets in dyn_lds)
+#define JD_SY_RINGS 0u
+#define JD_SY_DCSUM ((JD_SYNC_WG / 64u) * JD_SPEC_RING_BYTES)  // [3 components][JD_SYNC_WG lanes] ints
+#define JD_SY_CTAB (JD_SY_DCSUM + 3u * JD_SYNC_WG * 4u)         // per block-in-MCU: dcb | acb << 15 | comp << 30
+#define JD_SY_LUT (JD_SY_CTAB + 64u)
+
+__device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<int*>(__builtin_assume_aligned(dyn_lds + off, 4)); }
+
+__device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, uint32_t s, uint32_t entry,
+                                            uint32_t sbits, bool run, JdSub& rec) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t ring_l = ring_w + lane * 4u;                           // ring_w is 8192-aligned
+    const uint32_t ring_l = JD_SY_RINGS + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * JD_SPEC_RING_BYTES + lane * 4u;
     auto ring_at = [&](uint32_t xb) { return lds_u32(ring_l | (xb & (JD_SPEC_RING_BYTES - 1u))); };
+    const uint32_t dcs_l = JD_SY_DCSUM + threadIdx.x * 4u;
     // stream position: bit `start` of the unstuffed stream; data begins at quad 1 (front pad)
     const uint32_t start = s * JD_SUBSEQ_BITS + (entry & 0xFFu);
     uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
@@ -495,32 +504,29 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     // ring bookkeeping in units of 256 bytes per dword (= the [dword][lane] row pitch)
     uint32_t rpb = (g & 3u) * 256u, wqb = 0;
     auto top_up = [&]() {                                                 // every lane fills every free quad
-#pragma unroll 1
-        for (int round = 0; round < 2; round++) {
-            uint4 v[4]; bool take[4];
+        uint4 v[4]; bool take[4];
+        const uint32_t used = (wqb >> 10) - (rpb >> 10);                  // quads holding unread dwords
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t used = (wqb >> 10) - (rpb >> 10);          // quads holding unread dwords
-                take[k] = run && used + (uint32_t)k < 8u;
-                const uint32_t q = qbase + (wqb >> 10) + (uint32_t)k;
-                v[k] = make_uint4(0, 0, 0, 0);
-                if (take[k]) v[k] = Q[q < qmax ? q : qmax];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (take[k]) {
-                    const uint32_t x = wqb + (uint32_t)k * 1024u;
-                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | (x & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].x);
-                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 256u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].y);
-                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 512u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].z);
-                    *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 768u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].w);
-                }
-            }
-            uint32_t n = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) n += take[k] ? 1u : 0u;
-            wqb += n * 1024u;
+        for (int k = 0; k < 4; k++) {
+            take[k] = run && used + (uint32_t)k < JD_SPEC_RING_DW / 4u;
+            const uint32_t q = qbase + (wqb >> 10) + (uint32_t)k;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (take[k]) v[k] = Q[q < qmax ? q : qmax];
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (take[k]) {
+                const uint32_t x = wqb + (uint32_t)k * 1024u;
+                *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | (x & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].x);
+                *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 256u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].y);
+                *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 512u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].z);
+                *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 768u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].w);
+            }
+        }
+        uint32_t n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) n += take[k] ? 1u : 0u;
+        wqb += n * 1024u;
         wave_lds_order();
     };
     top_up();
@@ -530,10 +536,11 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     int left = run ? (int)(end - start) : 0;                              // bits of the sub-sequence still to decode
     uint32_t c = (entry >> 8) & 0xFFu, z = (entry >> 16) & 0x7Fu;
     if (c >= ik.bpm) c = 0;
-    uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;
-    uint32_t dcb = lut_b + sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u, acb = lut_b + sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
-    uint32_t nstart = 0, first = 0xFFFFFFFFu;
-    int a0 = 0, a1 = 0, a2 = 0;                                          // DC-difference sums per component
+    uint32_t t = lds_u32(JD_SY_CTAB + c * 4u);
+    uint32_t dcb = t & 0x7FFFu, acb = (t >> 15) & 0x7FFFu, csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
+    uint32_t nstart = 0, first = 0;
+    *lds_int(dcs_l) = 0; *lds_int(dcs_l + JD_SYNC_WG * 4u) = 0; *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u) = 0;
+    wave_lds_order();
     while (left > 0) {
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up();
         const uint32_t cand = ring_at(rpb);
@@ -545,23 +552,22 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
             e = (e && o) ? lds_u16(tb + (o << 1) + (((win >> (32 - JD_LUT_BITS - 6)) & 63u) << 1)) : 0u;
             if (e == 0) e = 1;                                            // speculative: step over one bit
         }
-        const uint32_t total = e & 31u, size = (e >> 5) & 15u, zinc = ((e >> 9) & 63u) + 1u;
+        const uint32_t total = e & 31u;
         if (z == 0) {                                                     // a block starts here: DC difference
             if (nstart == 0) first = (uint32_t)left;                      // kept as "bits left" at that point
             nstart++;
-            const int diff = extend_bits(win, total, size);
-            a0 += comp == 0 ? diff : 0; a1 += comp == 1 ? diff : 0; a2 += comp >= 2 ? diff : 0;
+            atomicAdd(lds_int(csum), extend_bits(win, total, (e >> 5) & 15u));   // ds_add, no return
         }
         sh -= (int)total; left -= (int)total;
         const bool r = sh < 0;
         w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
         sh += r ? 32 : 0; rpb += r ? 256u : 0u;
-        z += zinc;
+        z += ((e >> 9) & 63u) + 1u;
         if (z >= 64u) {                                                   // block complete: next block's tables
             z = 0;
             c = (c + 1u == ik.bpm) ? 0u : c + 1u;
-            comp = c < ik.nl ? 0u : c - ik.nl + 1u;
-            dcb = lut_b + sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u; acb = lut_b + sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
+            t = lds_u32(JD_SY_CTAB + c * 4u);
+            dcb = t & 0x7FFFu; acb = (t >> 15) & 0x7FFFu; csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
         }
     }
     wave_lds_order();
@@ -570,11 +576,12 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
         rec.exit = pack_state((uint32_t)(-left), c, z);
         rec.nstart = nstart;
         rec.first = nstart ? (end - start) - first + (entry & 0xFFu) : 0u;   // bit offset from the sub-sequence start
-        rec.dc[0] = a0; rec.dc[1] = a1; rec.dc[2] = a2;
+        rec.dc[0] = *lds_int(dcs_l); rec.dc[1] = *lds_int(dcs_l + JD_SYNC_WG * 4u); rec.dc[2] = *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u);
     }
 }
 
-// dyn_lds: [JD_SYNC_WG/64 rings of 8 KiB][lookup tables]
+// Workgroup w owns sub-sequences [w * JD_SYNC_OWN, (w + 1) * JD_SYNC_OWN); its lanes 0 .. JD_SYNC_WARM-1 warm up
+// on the JD_SYNC_WARM sub-sequences before them (results discarded).
 __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
     __shared__ uint32_t ex[JD_SYNC_WG];
     __shared__ uint32_t tmp[16];
@@ -584,44 +591,53 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
-    if (lw * JD_SYNC_WG >= nsub) return;                        // whole workgroup past the stream (uniform)
-    const uint32_t lut_b = (JD_SYNC_WG / 64u) * JD_SPEC_RING_BYTES;
-    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + lut_b), a.lut + im.lut_off, im.lut_len);
-    const uint32_t s = lw * JD_SYNC_WG + threadIdx.x;
-    const bool active = s < nsub;
+    if (lw * JD_SYNC_OWN >= nsub) return;                       // whole workgroup past the stream (uniform)
+    const ImgK ik = load_imgk(im);
+    if (threadIdx.x < 16u) {
+        const uint32_t cc = threadIdx.x < ik.bpm ? threadIdx.x : 0u;
+        const uint32_t comp = cc < ik.nl ? 0u : cc - ik.nl + 1u;
+        const uint32_t d = JD_SY_LUT + sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u, ac = JD_SY_LUT + sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
+        *reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_CTAB + threadIdx.x * 4u) = d | (ac << 15) | (comp << 30);
+    }
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + JD_SY_LUT), a.lut + im.lut_off, im.lut_len);
+    const int si = (int)(lw * JD_SYNC_OWN + threadIdx.x) - JD_SYNC_WARM;
+    const uint32_t s = si < 0 ? 0u : (uint32_t)si;
+    const bool owned = threadIdx.x >= JD_SYNC_WARM && s < nsub;
+    const bool active = fixup ? owned : (si >= 0 && s < nsub);
     const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
     const uint32_t qmax = (JD_STREAM_FRONT + slen + JD_STREAM_TAIL) / 16u - 1u;
-    const uint32_t ring_w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * JD_SPEC_RING_BYTES;
-    const ImgK ik = load_imgk(im);
     const uint32_t start_state = pack_state(0, 0, 0);
     JdSub rec; rec.entry = rec.exit = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0; rec.pad = 0;
     JdSub* gsub = a.sub + im.subseq_base;
     if (fixup) { if (active) rec = gsub[s]; }
-    else spec_decode(ik, Q, qmax, ring_w, lut_b, s, start_state, sbits, active, rec);
+    else spec_decode(ik, Q, qmax, s, start_state, sbits, active, rec);
     const uint32_t exit_before = rec.exit;
     uint32_t prev_wg_exit = 0;
-    if (threadIdx.x == 0 && s > 0 && fixup) prev_wg_exit = gsub[s - 1].exit;
+    if (threadIdx.x == JD_SYNC_WARM && s > 0 && fixup) prev_wg_exit = gsub[s - 1].exit;
     for (int it = 0; it <= JD_SYNC_WG; it++) {
         ex[threadIdx.x] = rec.exit;
         __syncthreads();
-        uint32_t ne;
-        if (threadIdx.x > 0) ne = ex[threadIdx.x - 1];
-        else if (s == 0) ne = start_state;
-        else ne = fixup ? prev_wg_exit : rec.entry;
+        uint32_t ne = rec.entry;
+        if (active) {
+            if (s == 0) ne = start_state;
+            else if (fixup && threadIdx.x == JD_SYNC_WARM) ne = prev_wg_exit;
+            else if (threadIdx.x > 0 && si > 0) ne = ex[threadIdx.x - 1];
+        }
         const bool changed = active && ne != rec.entry;
         if (!__syncthreads_or(changed)) break;
         if (__builtin_amdgcn_ballot_w64(changed))                // wave-uniform: skip waves with nothing to redo
-            spec_decode(ik, Q, qmax, ring_w, lut_b, s, ne, sbits, changed, rec);
+            spec_decode(ik, Q, qmax, s, ne, sbits, changed, rec);
     }
-    if (active) gsub[s] = rec;
+    if (owned) gsub[s] = rec;
     // workgroup totals for the spine scan
     uint32_t t0, t1, t2, t3;
-    block_excl_scan(active ? rec.nstart : 0u, tmp, t0);
-    block_excl_scan(active ? (uint32_t)rec.dc[0] : 0u, tmp, t1);
-    block_excl_scan(active ? (uint32_t)rec.dc[1] : 0u, tmp, t2);
-    block_excl_scan(active ? (uint32_t)rec.dc[2] : 0u, tmp, t3);
+    block_excl_scan(owned ? rec.nstart : 0u, tmp, t0);
+    block_excl_scan(owned ? (uint32_t)rec.dc[0] : 0u, tmp, t1);
+    block_excl_scan(owned ? (uint32_t)rec.dc[1] : 0u, tmp, t2);
+    block_excl_scan(owned ? (uint32_t)rec.dc[2] : 0u, tmp, t3);
     if (threadIdx.x == 0) a.sync_tot[im.sync_wg_base + lw] = make_uint4(t0, t1, t2, t3);
-    const uint32_t last = (nsub - lw * JD_SYNC_WG) < JD_SYNC_WG ? (nsub - lw * JD_SYNC_WG - 1u) : JD_SYNC_WG - 1u;
+    const uint32_t rem = nsub - lw * JD_SYNC_OWN;
+    const uint32_t last = JD_SYNC_WARM + (rem < JD_SYNC_OWN ? rem : JD_SYNC_OWN) - 1u;
     if (fixup && threadIdx.x == last && rec.exit != exit_before) atomicOr(&a.changed[flag_slot], 1u);
 }
 
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
     if (im.restart_interval != 0) return;
     const uint32_t sbits = a.stream_len[img] * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
-    uint32_t nwg = (nsub + JD_SYNC_WG - 1u) / JD_SYNC_WG;
+    uint32_t nwg = (nsub + JD_SYNC_OWN - 1u) / JD_SYNC_OWN;
     if (nwg > im.n_sync_wg) nwg = im.n_sync_wg;
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     for (uint32_t c0 = 0; c0 < nwg; c0 += 256) {
@@ -659,10 +675,10 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs 
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
-    if (lw * JD_SYNC_WG >= nsub) return;
+    if (lw * JD_SYNC_OWN >= nsub) return;
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.lut_off, im.lut_len);
-    const uint32_t s = lw * JD_SYNC_WG + threadIdx.x;
-    const bool active = s < nsub;
+    const uint32_t s = lw * JD_SYNC_OWN + threadIdx.x;          // same partition as the sync pass (last lanes idle)
+    const bool active = threadIdx.x < JD_SYNC_OWN && s < nsub;
     JdSub rec; rec.entry = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
     if (active) rec = a.sub[im.subseq_base + s];
     const uint4 base = a.sync_tot[im.sync_wg_base + lw];
@@ -916,7 +932,7 @@ void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t w
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 15u) & ~15u;
-    const uint32_t lds = (JD_SYNC_WG / 64u) * JD_SPEC_RING_BYTES + lb;
+    const uint32_t lds = JD_SY_LUT + lb;
     hipLaunchKernelGGL(k1_sync, dim3(wgs), dim3(JD_SYNC_WG), lds, s, x, fixup, flag_slot);
 }
 
