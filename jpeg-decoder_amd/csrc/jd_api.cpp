@@ -310,7 +310,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         if (f.restart_interval) b->any_dri = true; else b->any_nodri = true;
         // table set: per component (td, ta); identical (class,id) pairs share one packed table
         std::string key;
-        std::vector<uint16_t> set;
+        std::vector<uint16_t> set, sset;                          // writer tables / sync-pass twin (same layout)
         std::map<int, uint32_t> placed;                           // class*4+id -> entry offset in set
         for (int c = 0; c < f.ncomp; c++) {
             for (int cls = 0; cls < 2; cls++) {
@@ -320,6 +320,8 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
                 if (it == placed.end()) {
                     const uint32_t off = (uint32_t)set.size();
                     if (jd_pack_lut(h.bits, h.vals, h.nvals, cls == 0, set)) { delete b; return JD_E_TABLE; }
+                    if (cls == 0) jd_pack_lut(h.bits, h.vals, h.nvals, true, sset);
+                    else jd_pack_lut_multi(h.bits, h.vals, h.nvals, sset);
                     it = placed.emplace(cls * 4 + id, off).first;
                     key.append((const char*)h.bits, 16); key.append((const char*)h.vals, h.nvals); key.push_back((char)(cls * 4 + id));
                 }
@@ -328,11 +330,12 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
             key.push_back((char)(0x40 | (f.comp[c].td << 2) | f.comp[c].ta));
             memcpy(im.q[c], f.qt[f.comp[c].tq], 64);
         }
-        while (set.size() % 8) set.push_back(0);
+        while (set.size() % 8) { set.push_back(0); sset.push_back(0); }
         auto sit = seen.find(key);
         if (sit == seen.end()) {
             sit = seen.emplace(key, std::make_pair((uint32_t)lut.size(), (uint32_t)set.size())).first;
             lut.insert(lut.end(), set.begin(), set.end());
+            lut.insert(lut.end(), sset.begin(), sset.end());
         }
         im.lut_off = sit->second.first; im.lut_len = sit->second.second;
         b->max_lut_bytes = std::max<uint32_t>(b->max_lut_bytes, im.lut_len * 2u);

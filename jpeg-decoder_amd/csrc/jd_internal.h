@@ -69,6 +69,8 @@ struct JdImg {
     uint32_t subseq_base, n_subseq_cap, sync_wg_base, n_sync_wg;
     uint32_t lut_off, lut_len;   // u16 offset / length of this image's table set in the LUT buffer
     uint32_t dc_lut[3], ac_lut[3]; // per component: entry offset of its DC / AC table inside the set
+                                   // the sync pass's twin set (multi-symbol AC tables, same layout) follows at
+                                   // lut_off + lut_len
     uint32_t tile_base, n_tiles; // IDCT/colour tiles
     uint32_t pad0;
     uint64_t stream_off;         // byte offset of this image's region in the unstuffed buffer

@@ -489,15 +489,23 @@ static_assert(JD_SYNC_WG == 64 * JD_W_WAVES, "the write pass reuses the sync pas
 
 __device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<int*>(__builtin_assume_aligned(dyn_lds + off, 4)); }
 
-__device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, uint32_t s, uint32_t entry,
-                                            uint32_t sbits, bool run, JdSub& rec) {
+// COLD = the first, blind decode: it starts JD_COLD_BITS before the END of the sub-sequence (its only product is
+// a guess of the exit state, and a guess made from the last stretch is as good as one made from all of it)
+// and skips the block-start bookkeeping.
+#ifndef JD_COLD_BITS
+#define JD_COLD_BITS 2048u
+#endif
+template <bool COLD>
+__device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, const uint16_t* __restrict__ lutg,
+                                            uint32_t s, uint32_t entry, uint32_t sbits, bool run, JdSub& rec) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ring_l = JD_SY_RINGS + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * JD_SPEC_RING_BYTES + lane * 4u;
     auto ring_at = [&](uint32_t xb) { return lds_u32(ring_l | (xb & (JD_SPEC_RING_BYTES - 1u))); };
     const uint32_t dcs_l = JD_SY_DCSUM + threadIdx.x * 4u;
     // stream position: bit `start` of the unstuffed stream; data begins at quad 1 (front pad)
-    const uint32_t start = s * JD_SUBSEQ_BITS + (entry & 0xFFu);
     uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
+    uint32_t start = s * JD_SUBSEQ_BITS + (entry & 0xFFu);
+    if (COLD && end - start > JD_COLD_BITS) start = end - JD_COLD_BITS;
     const uint32_t o0 = ((start - 1u) & 31u) + 1u;
     const uint32_t g = ((start + 32u - o0) >> 5) + 3u;                    // dword (front pad included) that becomes w0
     const uint32_t qbase = (g >> 2) < qmax ? (g >> 2) : qmax;
@@ -552,17 +560,34 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
             e = (e && o) ? lds_u16(tb + (o << 1) + (((win >> (32 - JD_LUT_BITS - 6)) & 63u) << 1)) : 0u;
             if (e == 0) e = 1;                                            // speculative: step over one bit
         }
-        const uint32_t total = e & 31u;
+        uint32_t total = e & 31u;
+        uint32_t zn = z + ((e >> 5) & 127u);                              // AC entries: A + 64 * E (jd_tables.cpp)
         if (z == 0) {                                                     // a block starts here: DC difference
-            if (nstart == 0) first = (uint32_t)left;                      // kept as "bits left" at that point
-            nstart++;
-            atomicAdd(lds_int(csum), extend_bits(win, total, (e >> 5) & 15u));   // ds_add, no return
+            if (!COLD) {
+                if (nstart == 0) first = (uint32_t)left;                  // kept as "bits left" at that point
+                nstart++;
+                atomicAdd(lds_int(csum), extend_bits(win, total, (e >> 5) & 15u));   // ds_add, no return
+            }
+            zn = 1;
+        } else if (zn >= 64u) {
+            // the block ends in this group: fine if it ends with the group (index 64 reached by its last symbol, or
+            // EOB before index 64); if the block filled up INSIDE the group, the rest of the group belongs to the
+            // next block -- redo the step with one symbol from the writer's table
+            const bool ok = zn == 64u || (zn - z >= 64u && zn < 128u);
+            if (!ok) {
+                const uint16_t* gt = lutg + ((acb - JD_SY_LUT) >> 1);
+                uint32_t e1 = gt[win >> (32 - JD_LUT_BITS)];
+                if (e1 & 0x8000u) e1 = (e1 & 0x7FFFu) ? gt[(e1 & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)] : 0u;
+                if (e1 == 0) e1 = 1;
+                total = e1 & 31u;
+                zn = z + ((e1 >> 9) & 63u) + 1u;
+            }
         }
         sh -= (int)total; left -= (int)total;
         const bool r = sh < 0;
         w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
         sh += r ? 32 : 0; rpb += r ? 256u : 0u;
-        z += ((e >> 9) & 63u) + 1u;
+        z = zn;
         if (z >= 64u) {                                                   // block complete: next block's tables
             z = 0;
             c = (c + 1u == ik.bpm) ? 0u : c + 1u;
@@ -599,7 +624,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         const uint32_t d = JD_SY_LUT + sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u, ac = JD_SY_LUT + sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
         *reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_CTAB + threadIdx.x * 4u) = d | (ac << 15) | (comp << 30);
     }
-    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + JD_SY_LUT), a.lut + im.lut_off, im.lut_len);
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + JD_SY_LUT), a.lut + im.lut_off + im.lut_len, im.lut_len);   // sync twin set
     const int si = (int)(lw * JD_SYNC_OWN + threadIdx.x) - JD_SYNC_WARM;
     const uint32_t s = si < 0 ? 0u : (uint32_t)si;
     const bool owned = threadIdx.x >= JD_SYNC_WARM && s < nsub;
@@ -610,7 +635,12 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     JdSub rec; rec.entry = rec.exit = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0; rec.pad = 0;
     JdSub* gsub = a.sub + im.subseq_base;
     if (fixup) { if (active) rec = gsub[s]; }
-    else spec_decode(ik, Q, qmax, s, start_state, sbits, active, rec);
+    else {
+        // blind decode: only its exit state is kept; entry 0 (not a valid state) makes every lane decode again
+        // from its neighbour's exit in the first round of the loop below
+        spec_decode<true>(ik, Q, qmax, a.lut + im.lut_off, s, start_state, sbits, active && s != 0, rec);
+        rec.entry = 0;
+    }
     const uint32_t exit_before = rec.exit;
     uint32_t prev_wg_exit = 0;
     if (threadIdx.x == JD_SYNC_WARM && s > 0 && fixup) prev_wg_exit = gsub[s - 1].exit;
@@ -626,7 +656,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         const bool changed = active && ne != rec.entry;
         if (!__syncthreads_or(changed)) break;
         if (__builtin_amdgcn_ballot_w64(changed))                // wave-uniform: skip waves with nothing to redo
-            spec_decode(ik, Q, qmax, s, ne, sbits, changed, rec);
+            spec_decode<false>(ik, Q, qmax, a.lut + im.lut_off, s, ne, sbits, changed, rec);
     }
     if (owned) gsub[s] = rec;
     // workgroup totals for the spine scan

@@ -58,3 +58,41 @@ int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_
     }
     return 0;
 }
+
+// Sync-pass AC table.  The self-synchronising pass needs no AC values, only how far the stream and the zig-zag
+// index move, so its AC entries use their own format and a primary entry covers as many WHOLE run/size symbols
+// (code + magnitude bits) as fit in the JD_LUT_BITS-bit window:
+//   bit 15 = 0 : [4:0] total bits of the group, [11:5] A + 64*E where A = sum of (run + 1) of the group's
+//                symbols other than EOB (<= 63) and E = 1 when the group ends with EOB
+//   bit 15 = 1 : secondary table offset, as in the writer's tables;  0 = invalid
+// The kernel takes a group only when the block cannot have filled up (index 64 reached without EOB) inside it;
+// otherwise it falls back to one symbol from the writer's table.
+static inline uint16_t sync_entry(unsigned total, unsigned a, unsigned eob) { return (uint16_t)(total | ((a + 64u * eob) << 5)); }
+
+int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint16_t>& out) {
+    const size_t base = out.size();
+    const int rc = jd_pack_lut(bits, vals, nvals, false, out);
+    if (rc) return rc;
+    const std::vector<uint16_t> single(out.begin() + base, out.end());
+    for (size_t i = 0; i < single.size(); i++) {                  // every complete-symbol entry: new format
+        const uint16_t e = single[i];
+        if (e == 0 || (e & 0x8000u)) continue;
+        const unsigned zinc = ((e >> 9) & 63u) + 1u;
+        out[base + i] = zinc == 64 ? sync_entry(e & 31u, 0, 1) : sync_entry(e & 31u, zinc, 0);
+    }
+    for (unsigned w = 0; w < JD_LUT_PRIMARY; w++) {               // primary entries: greedy groups
+        unsigned pos = 0, a = 0, eob = 0, nsym = 0;
+        while (pos < JD_LUT_BITS && !eob) {
+            const uint16_t e = single[(w << pos) & (JD_LUT_PRIMARY - 1)];
+            if (e == 0 || (e & 0x8000u)) break;
+            const unsigned total = e & 31u, zinc = ((e >> 9) & 63u) + 1u;
+            if (pos + total > JD_LUT_BITS) break;                 // not wholly inside the known bits
+            if (zinc == 64) eob = 1;
+            else if (a + zinc > 63) break;
+            else a += zinc;
+            pos += total; nsym++;
+        }
+        if (nsym >= 2) out[base + w] = sync_entry(pos, a, eob);
+    }
+    return 0;
+}

@@ -9,3 +9,5 @@
 // Appends one packed table (JD_LUT_PRIMARY + 64 * n_secondary entries) to `out`.
 // Returns 0, -1 (counts do not match), -2 (not a prefix code), -3 (too large).
 int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, std::vector<uint16_t>& out);
+// AC table for the self-synchronising pass: several whole symbols per primary entry (see jd_tables.cpp).
+int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint16_t>& out);
