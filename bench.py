@@ -58,7 +58,7 @@ def cpu_baseline(workload, quality, detail):
     import jpeg_decoder_amd as jd
     if workload in ("c3", "c4"):
         w = h = 8192
-        n = 1
+        n = 3
     else:
         w, h, n = 1920, 1080, 6
     px, t_hot, t_wall = 0, 0.0, 0.0
@@ -152,6 +152,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    STAGE_KERNEL = {"unstuff": "k0_scatter", "huffman_intervals": "k1_write_intervals", "huffman_sync": "k1_sync",
+                    "huffman_write": "k1_write_subseq", "idct_colour": "k2_idct_colour"}
+
+    def recorded_traffic(kernel):
+        """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_b_traffic.json), if they were
+        taken on this workload and batch; PMC counters cannot be read from inside this process."""
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_b_traffic.json")))["workloads"][args.workload]
+            if rec["batch"] != batch:
+                return None
+            return rec["kernels"][kernel]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            return None
+
     if rank == 0:
         px_step = batch * w * h * world
         ms = dt / args.steps * 1e3
@@ -169,8 +183,9 @@ def main():
                        "images_per_gpu_per_step": batch, "distinct_images_per_gpu": distinct, "quality": args.quality,
                        "ecs_bytes_per_pixel": round(sum(lens) / (batch * w * h), 4), "restart_interval": ri,
                        "parallelism": "whole images per GPU, no collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(STAGE_KERNEL.get(dom, dom)),
                          "launch_us": round(stages[dom], 1), "algorithmic_bytes_per_launch": alg_bytes,
                          "stage_us": {k: round(v, 1) for k, v in stages.items()}, "runs_averaged": nruns},
         }
