@@ -17,6 +17,9 @@
 #include "jd_internal.h"
 
 #define WAVE 64
+#ifndef JD_K2_FORM
+#define JD_K2_FORM 1         // 1 = MCU per lane (no LDS, no barrier), 0 = block per lane with LDS exchange
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -862,7 +865,8 @@ __device__ __forceinline__ void k2_body(const JdKernelArgs& a, const JdImg& im, 
     {
         constexpr uint32_t ROWS = 8u * VS, ITEMS = ROWS * JD_TILE_MCUS * HS;
         const uint32_t rs = im.row_stride;
-        const bool al8 = ((rs & 7u) == 0) && ((reinterpret_cast<uintptr_t>(im.rgb) & 7u) == 0);
+        uint8_t* const rgbp = im.rgb;
+        const bool al8 = ((rs & 7u) == 0) && ((reinterpret_cast<uintptr_t>(rgbp) & 7u) == 0);
         for (uint32_t it = threadIdx.x; it < ITEMS; it += nthreads) {
             const uint32_t bx = it % HS, m = (it / HS) % JD_TILE_MCUS, r = it / (HS * JD_TILE_MCUS);
             if (m >= nm) continue;
@@ -902,7 +906,7 @@ __device__ __forceinline__ void k2_body(const JdKernelArgs& a, const JdImg& im, 
                     d[(3 * j + 2) >> 2] = put_u8(B, (3 * j + 2) & 3, d[(3 * j + 2) >> 2]);
                 }
             }
-            uint8_t* dst = im.rgb + (uint64_t)Yp * rs + X * 3u;
+            uint8_t* dst = rgbp + (uint64_t)Yp * rs + X * 3u;
             if (al8 && X + 8u <= im.width) {
                 uint2* o = reinterpret_cast<uint2*>(dst);
                 o[0] = make_uint2(d[0], d[1]); o[1] = make_uint2(d[2], d[3]); o[2] = make_uint2(d[4], d[5]);
@@ -931,6 +935,216 @@ __global__ __launch_bounds__(384, JD_K2_WPS) void k2_idct_colour(JdKernelArgs a,
     case 2: k2_body<2, 1, 3>(a, im, tile, K, origin); break;
     case 3: k2_body<1, 2, 3>(a, im, tile, K, origin); break;
     default: k2_body<2, 2, 3>(a, im, tile, K, origin); break;
+    }
+}
+
+// ---- K2, MCU-per-lane form -----------------------------------------------------------------------------
+// One lane owns one whole MCU, one wave owns 64 consecutive MCUs; waves never talk to each other: no LDS, no
+// barrier.  The lane runs the chroma blocks first and keeps their samples in registers (packed int16), then
+// each luma block: load 128 B of coefficients, dequantise + de-zigzag + both IDCT passes in registers, colour-
+// convert the 8 x 8 pixels against the chroma quadrant (PY>>1, PX>>1) and store 24-byte rows.  The block loop is
+// a real loop (the IDCT and colour code exist once); only the register shuffles that pick the chroma quadrant
+// are specialised per block.
+template <int HS, int VS, int NC>
+__device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im, uint32_t tile, const JdIdctConst& K) {
+    constexpr uint32_t NL = HS * VS, BPM = NL + NC - 1;
+    const uint32_t M = tile * 64u + (threadIdx.x & 63u);
+    if (M >= im.n_mcus) return;
+    const uint32_t my = M / im.mcux, mx = M - my * im.mcux;
+    const uint32_t X0 = mx * 8u * HS, Y0 = my * 8u * VS;
+    const uint4* __restrict__ cbase = reinterpret_cast<const uint4*>(a.coef + im.coef_off + (uint64_t)M * BPM * 64u);
+    const uint32_t rs = im.row_stride, W = im.width, H = im.height;
+    // a copy (stores through it must not force reloads of `im`), in the GLOBAL address space: a generic-pointer
+    // store could alias LDS, so hipcc would drain the LDS-DMA queue (and every earlier store) before each one
+    typedef __attribute__((address_space(1))) uint8_t g_u8;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) u32x2 g_u2;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) u32x4 g_u4;
+    g_u8* const rgbp = (g_u8*)im.rgb;
+    const bool al8 = ((rs & 7u) == 0) && ((reinterpret_cast<uintptr_t>(im.rgb) & 7u) == 0);
+    const bool al16 = ((rs & 15u) == 0) && ((reinterpret_cast<uintptr_t>(im.rgb) & 15u) == 0);
+    uint32_t chroma[2][32];                                        // [Cb, Cr][row * 4 + col / 2]: int16 pairs
+#pragma unroll
+    for (int i = 0; i < 32; i++) { chroma[0][i] = 0; chroma[1][i] = 0; }
+    // Coefficients come in through LDS-DMA (global_load_lds, no VGPRs): piece i of every lane's block lands at
+    // dyn_lds + i * 1024 + lane * 16, and the next block's eight pieces are in flight while this one is computed.
+    // dyn_lds + 8192 .. : the left luma block's RGB rows wait here (24 B per lane and row) for the right one.
+    const uint32_t lane = threadIdx.x & 63u;
+    auto block_of = [&](uint32_t st) { return st < (uint32_t)(NC - 1) ? NL + st : st - (uint32_t)(NC - 1); };   // chroma first
+    auto fetch = [&](uint32_t st) {
+        const uint4* src = cbase + block_of(st) * 8u;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                             (__attribute__((address_space(3))) void*)(dyn_lds + i * 1024),
+                                             16, 0, 0);
+    };
+    fetch(0);
+
+#pragma unroll 1
+    for (uint32_t st = 0; st < BPM; st++) {
+        const uint32_t b = __builtin_amdgcn_readfirstlane(block_of(st));
+        const uint32_t comp = b < NL ? 0u : b - NL + 1u;
+        // the quantisation table is wave-uniform: scalar loads (a vector load here would also drain the DMA queue)
+        uint32_t qw[16];
+        {
+            const uint32_t* qp = reinterpret_cast<const uint32_t*>(im.q[comp]);
+#pragma unroll
+            for (int i = 0; i < 16; i++) qw[i] = __builtin_amdgcn_readfirstlane(qp[i]);
+        }
+        uint32_t cw[32];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(dyn_lds + i * 1024 + lane * 16u);
+            cw[i * 4 + 0] = v.x; cw[i * 4 + 1] = v.y; cw[i * 4 + 2] = v.z; cw[i * 4 + 3] = v.w;
+        }
+        // the DMA of the next block reuses the buffer: the reads above must have returned first (LDS-DMA writes
+        // arrive through the vector-memory path and are not ordered behind ds_read)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (st + 1u < BPM) fetch(st + 1u);
+        int mid[64];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int x[8], o[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int zi = kZZ.n2z[r * 8 + j];
+                const int cv = (zi & 1) ? ((int)cw[zi >> 1] >> 16) : (int)(short)(cw[zi >> 1] & 0xFFFFu);
+                const int qv = (int)((qw[(r * 8 + j) >> 2] >> (((r * 8 + j) & 3) * 8)) & 0xFFu);
+                x[r] = __mul24(cv, qv);                             // dequantize, main.go:660-662
+            }
+            if (JD_K2_ABL & 1) { for (int r = 0; r < 8; r++) o[r] = x[r]; }
+            else idct_1d(K, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
+#pragma unroll
+            for (int r = 0; r < 8; r++) mid[r * 8 + j] = o[r];
+        }
+        uint32_t smp[32];                                          // the block's samples, saturated int16 pairs
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int o[8];
+            if (JD_K2_ABL & 1) { for (int r = 0; r < 8; r++) o[r] = mid[i * 8 + r]; }
+            else idct_1d(K, mid[i * 8 + 0], mid[i * 8 + 1], mid[i * 8 + 2], mid[i * 8 + 3], mid[i * 8 + 4], mid[i * 8 + 5],
+                    mid[i * 8 + 6], mid[i * 8 + 7], o);
+            typedef short short2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                union { short2v s; uint32_t u; } p;
+                p.s = __builtin_amdgcn_cvt_pk_i16(o[2 * k], o[2 * k + 1]);
+                smp[i * 4 + k] = p.u;
+            }
+        }
+        if (b >= NL) {                                             // wave-uniform
+            if (b == NL) {
+#pragma unroll
+                for (int i = 0; i < 32; i++) chroma[0][i] = smp[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; i++) chroma[1][i] = smp[i];
+            }
+            continue;
+        }
+        // chroma quadrant of this luma block: rows by*4 .. by*4+3, columns bx*4 .. bx*4+3
+        uint32_t cq[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) cq[c][i] = 0;
+#pragma unroll
+        for (uint32_t yb = 0; yb < NL; yb++) {
+            if (b == yb) {                                         // wave-uniform; static register indices inside
+                constexpr int dummy = 0; (void)dummy;
+                const uint32_t bx = yb % HS, by = yb / HS;
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        cq[c][r * 2 + 0] = chroma[c][(by * 4 + r) * 4 + bx * 2 + 0];
+                        cq[c][r * 2 + 1] = chroma[c][(by * 4 + r) * 4 + bx * 2 + 1];
+                    }
+            }
+        }
+        const uint32_t bx = b % HS, by = b / HS;
+        const uint32_t X = X0 + bx * 8u;
+        if (X >= W) continue;
+        const bool full = al8 && X + 8u <= W;
+        // HS = 2: the two luma blocks of a row band are stored together, 48 contiguous bytes per lane and row (a
+        // wave then writes 3 KiB runs); stores of 24 B at a 48-B pitch ran at 3 TB/s instead of 4.5
+        const bool pair = HS == 2 && al16 && X0 + 16u <= W;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {                              // chroma row r serves pixel rows 2r, 2r+1
+            float rc[4], gb[4], gr[4], bc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t cbw = cq[0][r * 2 + (k >> 1)], crw = cq[1][r * 2 + (k >> 1)];
+                const int cbi = (k & 1) ? ((int)cbw >> 16) : (int)(short)(cbw & 0xFFFFu);
+                const int cri = (k & 1) ? ((int)crw >> 16) : (int)(short)(crw & 0xFFFFu);
+                const float cb = (float)cbi, cr = (float)cri;
+                rc[k] = __fmul_rn(1.402f, cr); gb[k] = __fmul_rn(0.344f, cb); gr[k] = __fmul_rn(0.714f, cr);
+                bc[k] = __fmul_rn(1.772f, cb);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = 2 * r + h;
+                const uint32_t Yp = Y0 + by * 8u + (uint32_t)i;
+                uint32_t d[6] = { 0, 0, 0, 0, 0, 0 };
+                if (JD_K2_ABL & 2) { d[0] = smp[i * 4] ^ cq[0][r * 2]; d[1] = smp[i * 4 + 1] ^ cq[1][r * 2]; d[2] = smp[i * 4 + 2] ^ cq[0][r * 2 + 1]; d[3] = smp[i * 4 + 3] ^ cq[1][r * 2 + 1]; }
+                else
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t yw = smp[i * 4 + (j >> 1)];
+                    const int yi = (j & 1) ? ((int)yw >> 16) : (int)(short)(yw & 0xFFFFu);
+                    const float y = (float)yi;
+                    const int k = j >> 1;
+                    const float R = __fadd_rn(__fadd_rn(y, rc[k]), 128.0f);
+                    const float G = __fadd_rn(__fsub_rn(__fsub_rn(y, gb[k]), gr[k]), 128.0f);
+                    const float B = __fadd_rn(__fadd_rn(y, bc[k]), 128.0f);
+                    d[(3 * j) >> 2] = put_u8(R, (3 * j) & 3, d[(3 * j) >> 2]);
+                    d[(3 * j + 1) >> 2] = put_u8(G, (3 * j + 1) & 3, d[(3 * j + 1) >> 2]);
+                    d[(3 * j + 2) >> 2] = put_u8(B, (3 * j + 2) & 3, d[(3 * j + 2) >> 2]);
+                }
+                if (Yp < H && pair) {
+                    uint8_t* stage = dyn_lds + 8192u + (uint32_t)i * 1536u + lane * 24u;
+                    if (bx == 0) {
+                        *reinterpret_cast<uint2*>(stage) = make_uint2(d[0], d[1]);
+                        *reinterpret_cast<uint2*>(stage + 8) = make_uint2(d[2], d[3]);
+                        *reinterpret_cast<uint2*>(stage + 16) = make_uint2(d[4], d[5]);
+                    } else {
+                        const uint2 l0 = *reinterpret_cast<const uint2*>(stage), l1 = *reinterpret_cast<const uint2*>(stage + 8);
+                        const uint2 l2 = *reinterpret_cast<const uint2*>(stage + 16);
+                        g_u4* o = (g_u4*)(rgbp + (uint64_t)Yp * rs + X0 * 3u);
+                        o[0] = u32x4{ l0.x, l0.y, l1.x, l1.y }; o[1] = u32x4{ l2.x, l2.y, d[0], d[1] };
+                        o[2] = u32x4{ d[2], d[3], d[4], d[5] };
+                    }
+                } else if (Yp < H) {
+                    g_u8* dst = rgbp + (uint64_t)Yp * rs + X * 3u;
+                    if (full) {
+                        g_u2* o = (g_u2*)dst;
+                        o[0] = u32x2{ d[0], d[1] }; o[1] = u32x2{ d[2], d[3] }; o[2] = u32x2{ d[4], d[5] };
+                    } else {
+                        const uint32_t n = W - X < 8u ? W - X : 8u;
+#pragma unroll
+                        for (uint32_t k = 0; k < 24; k++)
+                            if (k < n * 3u) dst[k] = (uint8_t)(d[k >> 2] >> ((k & 3u) * 8u));
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, 2) void k2_mcu_lanes(JdKernelArgs a, JdIdctConst K) {
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    const uint32_t tile = blockIdx.x - a.prefix[img];
+    const uint32_t mode = im.ncomp == 1 ? 0u : im.hs + 2u * im.vs - 2u;   // 1: 1x1, 2: 2x1, 3: 1x2, 4: 2x2
+    switch (mode) {                                                // wave-uniform
+    case 0: k2m_body<1, 1, 1>(a, im, tile, K); break;
+    case 1: k2m_body<1, 1, 3>(a, im, tile, K); break;
+    case 2: k2m_body<2, 1, 3>(a, im, tile, K); break;
+    case 3: k2m_body<1, 2, 3>(a, im, tile, K); break;
+    default: k2m_body<2, 2, 3>(a, im, tile, K); break;
     }
 }
 
@@ -985,7 +1199,12 @@ void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uin
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lds = JD_TILE_MCUS * (max_bpm * 128u + 16u);
+#if JD_K2_FORM == 1
+    (void)lds;
+    hipLaunchKernelGGL(k2_mcu_lanes, dim3(wgs), dim3(64), 8192 + 8 * 1536, s, x, K);
+#else
     hipLaunchKernelGGL(k2_idct_colour, dim3(wgs), dim3(64 * max_bpm), lds, s, x, K);
+#endif
 }
 
 }  // extern "C"
