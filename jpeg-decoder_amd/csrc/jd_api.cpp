@@ -165,7 +165,7 @@ struct jd_batch {
     uint8_t* d_ecs_own = nullptr; uint8_t* d_rgb_own = nullptr; uint8_t* d_stream = nullptr;
     int16_t* d_coef = nullptr; uint16_t* d_lut = nullptr;
     uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
-    uint2* d_k0 = nullptr; JdSub* d_sub = nullptr; uint4* d_sync_tot = nullptr;
+    unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; uint4* d_sync_tot = nullptr;
     uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_tile = nullptr;
     std::vector<uint32_t> pre_k0, pre_iv, pre_sync, pre_tile;
     std::vector<std::pair<size_t, size_t>> clear_ranges;   // coefficient ranges (int16 offset, count) that need zero-fill
@@ -196,7 +196,7 @@ JdKernelArgs kernel_args(const jd_batch* b) {
     JdKernelArgs a;
     a.imgs = b->d_img; a.n_images = b->n; a.prefix = nullptr; a.stream = b->d_stream; a.coef = b->d_coef;
     a.lut = b->d_lut; a.status = b->d_status; a.stream_len = b->d_stream_len; a.interval_start = b->d_interval;
-    a.k0_part = b->d_k0; a.sub = b->d_sub; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
+    a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
     return a;
 }
 
@@ -370,7 +370,8 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
     A(dev_alloc(&b->d_stream_len, (size_t)n_images, &tot));
     A(dev_alloc(&b->d_interval, (size_t)ivb, &tot));
     A(dev_alloc(&b->d_changed, (size_t)64, &tot));
-    A(dev_alloc(&b->d_k0, (size_t)k0c, &tot));
+    A(dev_alloc(&b->d_k0, (size_t)k0c + 32, &tot));
+    A(dev_alloc(&b->d_ticket, (size_t)64, &tot));
     A(dev_alloc(&b->d_sub, (size_t)subb, &tot));
     A(dev_alloc(&b->d_sync_tot, (size_t)swb, &tot));
     A(dev_alloc(&b->d_pre_k0, (size_t)n_images + 1, &tot));
@@ -395,7 +396,7 @@ extern "C" void jd_batch_destroy(jd_batch* b) {
     (void)hipSetDevice(b->device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     void* ptrs[] = { b->d_img, b->d_ecs_own, b->d_rgb_own, b->d_stream, b->d_coef, b->d_lut, b->d_status, b->d_stream_len,
-                     b->d_interval, b->d_changed, b->d_k0, b->d_sub, b->d_sync_tot, b->d_pre_k0, b->d_pre_iv, b->d_pre_sync,
+                     b->d_interval, b->d_changed, b->d_k0, b->d_ticket, b->d_sub, b->d_sync_tot, b->d_pre_k0, b->d_pre_iv, b->d_pre_sync,
                      b->d_pre_tile };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : b->events) (void)hipEventDestroy(e);

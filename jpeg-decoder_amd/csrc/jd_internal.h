@@ -31,7 +31,7 @@
 
 // unstuff pass: bytes per workgroup
 #define JD_K0_THREADS 256
-#define JD_K0_CHUNK (JD_K0_THREADS * 16)
+#define JD_K0_CHUNK (JD_K0_THREADS * 64)
 
 // unstuffed stream: bytes of padding in front of / behind each image's data
 #define JD_STREAM_FRONT 16
@@ -105,7 +105,8 @@ struct JdKernelArgs {
     uint32_t* status;            // per image
     uint32_t* stream_len;        // per image: unstuffed byte count
     uint32_t* interval_start;
-    uint2* k0_part;              // per K0 chunk: (kept bytes, RST markers) -> exclusive prefix after spine
+    unsigned long long* k0_state; // per K0 chunk: look-back status word (jd_kernels.hip)
+    uint32_t* k0_ticket;         // chunk ticket counter (64 words, word 0 used)
     JdSub* sub;
     uint4* sync_tot;             // per sync workgroup: (block starts, dc0, dc1, dc2) totals -> exclusive prefix after spine
     uint32_t* changed;           // sync: set when a workgroup's exit state changed

@@ -65,138 +65,179 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 //   FF followed by FF      -> fill byte, drop the first FF
 //   FF followed by other   -> marker inside the segment: error (main.go:1013-1016)
 // ------------------------------------------------------------------------------------------------
-struct K0Bytes { uint32_t w[4]; uint32_t prev, next; uint32_t n; };
+// One pass, one kernel (k0_unstuff): every workgroup takes the next 16 KiB chunk of the batch (ticket counter, so
+// chunks start in order), classifies its bytes four at a time with SWAR flag words, scans the kept-byte and
+// marker counts, and learns its output offset by DECOUPLED LOOK-BACK over the per-chunk status words of the
+// chunks before it (aggregate / inclusive-prefix in one 8-byte word, written and read with agent-scope
+// relaxed atomics -- the value and its tag travel together, so no fence is involved).  The ECS is read once
+// and the unstuffed stream written once.
+#define JD_K0_QUADS 4                                          // 16-byte quads per thread
+static_assert(JD_K0_CHUNK == JD_K0_THREADS * 16 * JD_K0_QUADS, "chunk size");
 
-__device__ __forceinline__ uint32_t k0_byte(const K0Bytes& b, int j) { return (b.w[j >> 2] >> ((j & 3) * 8)) & 0xFF; }
-
-__device__ __forceinline__ void k0_load(const uint8_t* __restrict__ ecs, uint32_t len, uint32_t g0, K0Bytes& b) {
-    b.n = g0 < len ? (len - g0 < 16 ? len - g0 : 16) : 0;
-    b.w[0] = b.w[1] = b.w[2] = b.w[3] = 0;
-    if (b.n == 16) {
-        uint4 v = *reinterpret_cast<const uint4*>(ecs + g0);
-        b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
-    } else if (b.n) {
-#pragma unroll
-        for (int j = 0; j < 16; j++)                     // static indices: keeps w[] in registers
-            if ((uint32_t)j < b.n) b.w[j >> 2] |= (uint32_t)ecs[g0 + j] << ((j & 3) * 8);
-    }
-    b.prev = (g0 > 0 && b.n) ? ecs[g0 - 1] : 0;
-    b.next = (g0 + 16 < len) ? ecs[g0 + 16] : 0xD9;      // past the segment: behaves like EOI
+__device__ __forceinline__ uint32_t zero_flags(uint32_t x) {   // 0x80 in every byte of x that is zero (exact)
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
 }
 
-// keep / rst / bad masks (bit j = byte j of this thread)
-__device__ __forceinline__ void k0_classify(const K0Bytes& b, uint32_t& keep, uint32_t& rst, uint32_t& bad) {
-    keep = rst = bad = 0;
-    uint32_t p = b.prev;
+// keep / rst flag words (0x80 in byte j = byte j of the quad) and a non-zero `bad` if a non-RST marker follows FF
+__device__ __forceinline__ void k0_classify(const uint32_t (&w)[4], uint32_t prev, uint32_t next, uint32_t n,
+                                            uint32_t (&keep)[4], uint32_t (&rst)[4], uint32_t& bad) {
+    uint32_t F[4], Z[4], R[4];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        uint32_t c = k0_byte(b, j);
-        uint32_t nx = (j < 15) ? k0_byte(b, j + 1) : b.next;
-        if ((uint32_t)j + 1 == b.n) nx = b.next;
-        // branch-free on purpose: hipcc turns an if/else chain that ORs into one of three masks into a
-        // pointer select through scratch memory
-        const uint32_t valid = (uint32_t)j < b.n;
-        const uint32_t isff = c == 0xFF, pff = p == 0xFF;
-        const uint32_t isrst = (c >= 0xD0) & (c <= 0xD7);
-        const uint32_t k = isff ? (uint32_t)(nx == 0x00) : (pff ^ 1u);
-        const uint32_t r = (isff ^ 1u) & pff & isrst;
-        const uint32_t d = (isff ^ 1u) & pff & (uint32_t)(c != 0x00) & (isrst ^ 1u);
-        keep |= (k & valid) << j;
-        rst |= (r & valid) << j;
-        bad |= (d & valid) << j;
-        p = c;
+    for (int k = 0; k < 4; k++) {
+        F[k] = zero_flags(~w[k]); Z[k] = zero_flags(w[k]); R[k] = zero_flags((w[k] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u);
+    }
+    const uint32_t Fm1 = prev == 0xFFu ? 0x80000000u : 0u, Z4 = next == 0u ? 0x80u : 0u;
+    bad = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t PF = __builtin_amdgcn_alignbit(F[k], k ? F[k - 1] : Fm1, 24);       // previous byte is FF
+        const uint32_t NZ = __builtin_amdgcn_alignbit(k < 3 ? Z[k + 1] : Z4, Z[k], 8);     // next byte is 00
+        const uint32_t lo = 4u * (uint32_t)k;
+        const uint32_t V = n >= lo + 4u ? 0x80808080u : (n <= lo ? 0u : (0x80808080u & ((1u << (8u * (n - lo))) - 1u)));
+        const uint32_t after = ~F[k] & PF & V;                                             // non-FF byte right after an FF
+        keep[k] = ((F[k] & NZ) | (~F[k] & ~PF)) & V;
+        rst[k] = after & R[k];
+        bad |= after & ~Z[k] & ~R[k];
     }
 }
 
-__global__ __launch_bounds__(JD_K0_THREADS) void k0_count(JdKernelArgs a) {
-    __shared__ uint32_t red[16];
-    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
-    const JdImg& im = a.imgs[img];
-    const uint32_t chunk = blockIdx.x - a.prefix[img];
-    const uint32_t g0 = chunk * JD_K0_CHUNK + threadIdx.x * 16;
-    K0Bytes b; k0_load(im.ecs, im.ecs_len, g0, b);
-    uint32_t keep, rst, bad; k0_classify(b, keep, rst, bad);
-    uint32_t v = __popc(keep) | (__popc(rst) << 16);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) red[wv] = v;
-    if (__any(bad != 0) && lane == 0) atomicOr(&a.status[img], JD_ST_MARKER);
+// status word of a chunk: [27:0] kept bytes, [55:28] RSTn markers, [63:62] 1 = this chunk alone, 2 = inclusive prefix
+#define JD_K0_AGG (1ull << 62)
+#define JD_K0_PFX (2ull << 62)
+
+__global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
+    __shared__ uint32_t tmp[16];
+    __shared__ uint32_t s_chunk;
+    __shared__ uint2 s_base;
+    __shared__ __align__(16) uint8_t raw[JD_K0_CHUNK];
+    __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 32];
+    if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = red[0] + red[1] + red[2] + red[3];
-        a.k0_part[im.k0_chunk_base + chunk] = make_uint2(t & 0xFFFF, t >> 16);
-    }
-}
-
-// one workgroup per image: exclusive prefix over its chunks, stream length, marker count check
-__global__ __launch_bounds__(1024) void k0_spine(JdKernelArgs a) {
-    __shared__ uint32_t tmp[16];
-    const int img = blockIdx.x;
+    const uint32_t gchunk = s_chunk;                             // chunk index in the batch, in order of arrival
+    const int img = find_image(a.prefix, a.n_images, gchunk);
     const JdImg& im = a.imgs[img];
-    if (im.flags & JD_IMG_UNSTUFFED_INPUT) return;
-    uint32_t run_k = 0, run_r = 0;
-    for (uint32_t c0 = 0; c0 < im.n_k0_chunks; c0 += 1024) {
-        const uint32_t c = c0 + threadIdx.x;
-        uint2 v = c < im.n_k0_chunks ? a.k0_part[im.k0_chunk_base + c] : make_uint2(0, 0);
-        uint32_t tk, tr;
-        uint32_t ek = block_excl_scan(v.x, tmp, tk);
-        uint32_t er = block_excl_scan(v.y, tmp, tr);
-        if (c < im.n_k0_chunks) a.k0_part[im.k0_chunk_base + c] = make_uint2(run_k + ek, run_r + er);
-        run_k += tk; run_r += tr;
-    }
-    if (threadIdx.x == 0) {
-        a.stream_len[img] = run_k;
-        a.interval_start[im.interval_base] = 0;
-        a.interval_start[im.interval_base + im.n_intervals] = run_k;
-        if (run_r != im.n_intervals - 1) atomicOr(&a.status[img], JD_ST_RST_COUNT);
-    }
-}
-
-__global__ __launch_bounds__(JD_K0_THREADS) void k0_scatter(JdKernelArgs a) {
-    __shared__ uint32_t tmp[16];
-    __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 16];
-    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
-    const JdImg& im = a.imgs[img];
-    const uint32_t chunk = blockIdx.x - a.prefix[img];
-    const uint32_t g0 = chunk * JD_K0_CHUNK + threadIdx.x * 16;
-    K0Bytes b; k0_load(im.ecs, im.ecs_len, g0, b);
-    uint32_t keep, rst, bad; k0_classify(b, keep, rst, bad);
-    const uint2 base = a.k0_part[im.k0_chunk_base + chunk];     // exclusive prefix within the image
-    uint32_t tk, tr;
-    const uint32_t ek = block_excl_scan(__popc(keep), tmp, tk);
-    const uint32_t er = block_excl_scan(__popc(rst), tmp, tr);
-    const uint32_t al = base.x & 3;                              // keep LDS and global dword phases equal
-    uint32_t o = al + ek;
+    const uint32_t chunk = gchunk - a.prefix[img];
+    const uint8_t* __restrict__ ecs = im.ecs;
+    const uint32_t len = im.ecs_len, c0 = chunk * JD_K0_CHUNK;
+    // ---- stage the chunk: coalesced 16-byte loads (0xD9 past the end: behaves like EOI) ------------------
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        if (keep & (1u << j)) buf[o++] = (uint8_t)k0_byte(b, j);
-    }
-    if (rst) {
-        uint32_t ridx = base.y + er;                             // markers before this thread
+    for (int r = 0; r < JD_K0_QUADS; r++) {
+        const uint32_t q = (uint32_t)r * JD_K0_THREADS + threadIdx.x, g = c0 + q * 16u;
+        uint4 v = make_uint4(0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u);
+        if (g + 16u <= len) v = *reinterpret_cast<const uint4*>(ecs + g);
+        else if (g < len) {
+            uint32_t t[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (rst & (1u << j)) {
-                const uint32_t k = ridx + 1;                     // interval that starts after this marker
-                const uint32_t off = base.x + ek + __popc(keep & ((1u << j) - 1));
-                if (k < im.n_intervals) a.interval_start[im.interval_base + k] = off;
-                if ((k0_byte(b, j) & 7) != (ridx & 7)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
-                ridx++;
+            for (int j = 0; j < 16; j++)
+                if (g + (uint32_t)j < len) t[j >> 2] = (t[j >> 2] & ~(0xFFu << ((j & 3) * 8))) | ((uint32_t)ecs[g + j] << ((j & 3) * 8));
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        *reinterpret_cast<uint4*>(raw + q * 16u) = v;
+    }
+    const uint32_t edge_prev = c0 > 0 ? ecs[c0 - 1] : 0u;
+    const uint32_t edge_next = c0 + JD_K0_CHUNK < len ? ecs[c0 + JD_K0_CHUNK] : 0xD9u;
+    __syncthreads();
+    // ---- classify this thread's 64 contiguous bytes --------------------------------------------------------
+    const uint32_t t0 = threadIdx.x * 16u * JD_K0_QUADS;         // byte offset inside the chunk
+    uint32_t w[JD_K0_QUADS][4], keep[JD_K0_QUADS][4], rst[JD_K0_QUADS][4];
+    uint32_t bad = 0, nk = 0, nr = 0;
+#pragma unroll
+    for (int r = 0; r < JD_K0_QUADS; r++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(raw + t0 + r * 16);
+        w[r][0] = v.x; w[r][1] = v.y; w[r][2] = v.z; w[r][3] = v.w;
+    }
+#pragma unroll
+    for (int r = 0; r < JD_K0_QUADS; r++) {
+        const uint32_t o = t0 + (uint32_t)r * 16u, g = c0 + o;
+        const uint32_t prev = r ? (w[r - 1][3] >> 24) : (o ? raw[o - 1] : edge_prev);
+        const uint32_t next = r + 1 < JD_K0_QUADS ? (w[r + 1][0] & 0xFFu) : (o + 16u < JD_K0_CHUNK ? raw[o + 16u] : edge_next);
+        const uint32_t n = g < len ? (len - g < 16u ? len - g : 16u) : 0u;
+        uint32_t bq;
+        k0_classify(w[r], prev, next, n, keep[r], rst[r], bq);
+        bad |= bq;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { nk += __popc(keep[r][k]); nr += __popc(rst[r][k]); }
+    }
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&a.status[img], JD_ST_MARKER);
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(nk | (nr << 16), tmp, tot);   // nk <= 64 * 256 < 2^16 per workgroup
+    const uint32_t ek = ex & 0xFFFFu, er = ex >> 16, tk = tot & 0xFFFFu, tr = tot >> 16;
+    // ---- publish, look back, publish ------------------------------------------------------------------------
+    unsigned long long* st = a.k0_state + gchunk;
+    if (threadIdx.x < 64) {                                      // wave 0
+        const uint32_t lane = threadIdx.x;
+        const unsigned long long mine = (unsigned long long)tk | ((unsigned long long)tr << 28);
+        if (lane == 0) __hip_atomic_store(st, mine | (chunk ? JD_K0_AGG : JD_K0_PFX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long run = 0;                              // sum of the chunks before this one
+        int back = (int)chunk - 1;                               // nearest chunk not yet summed
+        while (back >= 0) {
+            const int idx = back - (int)lane;
+            unsigned long long v = JD_K0_PFX;                    // before the image's first chunk: prefix 0
+            if (idx >= 0) {
+                do { v = __hip_atomic_load(st - (chunk - (uint32_t)idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                while ((v >> 62) == 0);                          // the chunk took its ticket before us: it will publish
+            }
+            const unsigned long long pf = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
+            const uint32_t stop = pf ? (uint32_t)__builtin_ctzll(pf) : 64u;   // nearest chunk with an inclusive prefix
+            unsigned long long part = lane <= stop ? (v & ~(3ull << 62)) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+            run += part;
+            if (pf) break;
+            back -= 64;
+        }
+        if (lane == 0) {
+            if (chunk) __hip_atomic_store(st, (run + mine) | JD_K0_PFX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = make_uint2((uint32_t)(run & 0xFFFFFFFull), (uint32_t)((run >> 28) & 0xFFFFFFFull));
+            if (chunk + 1 == im.n_k0_chunks) {                   // last chunk of the image: totals
+                const uint32_t total = (uint32_t)((run + mine) & 0xFFFFFFFull), nrst = (uint32_t)(((run + mine) >> 28) & 0xFFFFFFFull);
+                a.stream_len[img] = total;
+                a.interval_start[im.interval_base] = 0;
+                a.interval_start[im.interval_base + im.n_intervals] = total;
+                if (nrst != im.n_intervals - 1) atomicOr(&a.status[img], JD_ST_RST_COUNT);
             }
         }
     }
     __syncthreads();
-    uint8_t* dst = a.stream + im.stream_off + JD_STREAM_FRONT + (base.x - al);   // dword aligned
+    const uint2 base = s_base;                                   // kept bytes / markers before this chunk
+    // ---- compact into LDS at the output's 16-byte phase, index the restart markers -----------------------------
+    const uint32_t al = base.x & 15u;
+    uint32_t o = al + ek;
+#pragma unroll
+    for (int r = 0; r < JD_K0_QUADS; r++)
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (keep[r][j >> 2] & (0x80u << ((j & 3) * 8))) buf[o++] = (uint8_t)(w[r][j >> 2] >> ((j & 3) * 8));
+    if (nr) {
+        uint32_t ridx = base.y + er, kb = base.x + ek;           // markers / kept bytes before the current byte
+#pragma unroll
+        for (int r = 0; r < JD_K0_QUADS; r++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t bit = 0x80u << ((j & 3) * 8);
+                if (rst[r][j >> 2] & bit) {
+                    const uint32_t k = ridx + 1;                 // interval that starts after this marker
+                    if (k < im.n_intervals) a.interval_start[im.interval_base + k] = kb;
+                    if (((w[r][j >> 2] >> ((j & 3) * 8)) & 7u) != (ridx & 7u)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
+                    ridx++;
+                }
+                if (keep[r][j >> 2] & bit) kb++;
+            }
+    }
+    __syncthreads();
+    // ---- LDS -> stream: whole 16-byte quads, bytes at the two ragged ends -------------------------------------
+    uint8_t* dst = a.stream + im.stream_off + JD_STREAM_FRONT + (base.x - al);   // 16-byte aligned
     const uint32_t lo = al, hi = al + tk;                        // valid byte range in buf
-    const uint32_t dlo = (lo + 3) >> 2, dhi = hi >> 2;           // full dwords [dlo, dhi)
-    for (uint32_t d = dlo + threadIdx.x; d < dhi; d += JD_K0_THREADS)
-        reinterpret_cast<uint32_t*>(dst)[d] = reinterpret_cast<const uint32_t*>(buf)[d];
-    if (threadIdx.x < 8) {                                       // ragged head / tail bytes
+    const uint32_t qlo = (lo + 15u) >> 4, qhi = hi >> 4;         // whole quads [qlo, qhi)
+    for (uint32_t q = qlo + threadIdx.x; q < qhi; q += JD_K0_THREADS)
+        reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(buf)[q];
+    if (threadIdx.x < 32) {
         uint32_t i;
-        if (threadIdx.x < 4) { i = lo + threadIdx.x; if (i < hi && i < (dlo << 2)) dst[i] = buf[i]; }
+        if (threadIdx.x < 16) { i = lo + threadIdx.x; if (i < hi && i < (qlo << 4)) dst[i] = buf[i]; }
         else {
-            uint32_t t0 = dhi << 2; if (t0 < (dlo << 2)) t0 = dlo << 2;
-            i = t0 + (threadIdx.x - 4);
+            uint32_t t1 = qhi << 4; if (t1 < (qlo << 4)) t1 = qlo << 4;
+            i = t1 + (threadIdx.x - 16);
             if (i >= lo && i < hi) dst[i] = buf[i];
         }
     }
@@ -1156,9 +1197,10 @@ extern "C" {
 void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t wgs, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix_k0;
-    hipLaunchKernelGGL(k0_count, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
-    hipLaunchKernelGGL(k0_spine, dim3(a.n_images), dim3(1024), 0, s, x);
-    hipLaunchKernelGGL(k0_scatter, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
+    // ticket counter + per-chunk status words start at zero every run (memsets of >= 256 bytes on the stream)
+    (void)hipMemsetAsync(a.k0_ticket, 0, 256, s);
+    (void)hipMemsetAsync(a.k0_state, 0, ((size_t)wgs * 8 + 255) & ~(size_t)255, s);
+    hipLaunchKernelGGL(k0_unstuff, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
 }
 
 void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
