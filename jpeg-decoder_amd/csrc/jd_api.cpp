@@ -371,7 +371,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
     A(dev_alloc(&b->d_interval, (size_t)ivb, &tot));
     A(dev_alloc(&b->d_changed, (size_t)64, &tot));
     A(dev_alloc(&b->d_k0, (size_t)k0c + 32, &tot));
-    A(dev_alloc(&b->d_ticket, (size_t)64, &tot));
+    A(dev_alloc(&b->d_ticket, (size_t)n_images + 64, &tot));
     A(dev_alloc(&b->d_sub, (size_t)subb, &tot));
     A(dev_alloc(&b->d_sync_tot, (size_t)swb, &tot));
     A(dev_alloc(&b->d_pre_k0, (size_t)n_images + 1, &tot));

@@ -106,7 +106,7 @@ struct JdKernelArgs {
     uint32_t* stream_len;        // per image: unstuffed byte count
     uint32_t* interval_start;
     unsigned long long* k0_state; // per K0 chunk: look-back status word (jd_kernels.hip)
-    uint32_t* k0_ticket;         // chunk ticket counter (64 words, word 0 used)
+    uint32_t* k0_ticket;         // per image: next chunk to hand out
     JdSub* sub;
     uint4* sync_tot;             // per sync workgroup: (block starts, dc0, dc1, dc2) totals -> exclusive prefix after spine
     uint32_t* changed;           // sync: set when a workgroup's exit state changed

@@ -110,14 +110,17 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
     __shared__ uint32_t tmp[16];
     __shared__ uint32_t s_chunk;
     __shared__ uint2 s_base;
-    __shared__ __align__(16) uint8_t raw[JD_K0_CHUNK];
-    __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 32];
-    if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket, 1u);
-    __syncthreads();
-    const uint32_t gchunk = s_chunk;                             // chunk index in the batch, in order of arrival
-    const int img = find_image(a.prefix, a.n_images, gchunk);
+    __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 32];   // first the raw chunk, then (after the scan's barriers) the compacted one
+    uint8_t* const raw = buf;
+    // blockIdx picks the image; the chunk inside it is the next ticket of THAT image (one counter for the whole
+    // batch saturates at ~90 tickets/us -- measured 80 us for 7,200 chunks), so a chunk's predecessors have
+    // always started before it
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
-    const uint32_t chunk = gchunk - a.prefix[img];
+    if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket + img, 1u);
+    __syncthreads();
+    const uint32_t chunk = s_chunk;
+    const uint32_t gchunk = a.prefix[img] + chunk;
     const uint8_t* __restrict__ ecs = im.ecs;
     const uint32_t len = im.ecs_len, c0 = chunk * JD_K0_CHUNK;
     // ---- stage the chunk: coalesced 16-byte loads (0xD9 past the end: behaves like EOI) ------------------
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
     __syncthreads();
     // ---- classify this thread's 64 contiguous bytes --------------------------------------------------------
     const uint32_t t0 = threadIdx.x * 16u * JD_K0_QUADS;         // byte offset inside the chunk
-    uint32_t w[JD_K0_QUADS][4], keep[JD_K0_QUADS][4], rst[JD_K0_QUADS][4];
+    uint32_t w[JD_K0_QUADS][4], keep[JD_K0_QUADS][4], prevb[JD_K0_QUADS];
     uint32_t bad = 0, nk = 0, nr = 0;
 #pragma unroll
     for (int r = 0; r < JD_K0_QUADS; r++) {
@@ -153,11 +156,11 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
         const uint32_t prev = r ? (w[r - 1][3] >> 24) : (o ? raw[o - 1] : edge_prev);
         const uint32_t next = r + 1 < JD_K0_QUADS ? (w[r + 1][0] & 0xFFu) : (o + 16u < JD_K0_CHUNK ? raw[o + 16u] : edge_next);
         const uint32_t n = g < len ? (len - g < 16u ? len - g : 16u) : 0u;
-        uint32_t bq;
-        k0_classify(w[r], prev, next, n, keep[r], rst[r], bq);
-        bad |= bq;
+        uint32_t bq, rq[4];
+        k0_classify(w[r], prev, next, n, keep[r], rq, bq);
+        bad |= bq; prevb[r] = prev | (n << 8);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { nk += __popc(keep[r][k]); nr += __popc(rst[r][k]); }
+        for (int k = 0; k < 4; k++) { nk += __popc(keep[r][k]); nr += __popc(rq[k]); }
     }
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&a.status[img], JD_ST_MARKER);
     uint32_t tot;
@@ -209,21 +212,28 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if (keep[r][j >> 2] & (0x80u << ((j & 3) * 8))) buf[o++] = (uint8_t)(w[r][j >> 2] >> ((j & 3) * 8));
-    if (nr) {
-        uint32_t ridx = base.y + er, kb = base.x + ek;           // markers / kept bytes before the current byte
+    if (nr) {                                                    // markers are rare: walk the set flags only
+        uint32_t ridx = base.y + er, kb = base.x + ek;           // markers / kept bytes before the current quad
 #pragma unroll
-        for (int r = 0; r < JD_K0_QUADS; r++)
+        for (int r = 0; r < JD_K0_QUADS; r++) {
+            uint32_t kq[4], rq[4], bq;                           // marker flags are recomputed here, not kept live
+            k0_classify(w[r], prevb[r] & 0xFFu, 0xD9u, prevb[r] >> 8, kq, rq, bq);
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t bit = 0x80u << ((j & 3) * 8);
-                if (rst[r][j >> 2] & bit) {
-                    const uint32_t k = ridx + 1;                 // interval that starts after this marker
-                    if (k < im.n_intervals) a.interval_start[im.interval_base + k] = kb;
-                    if (((w[r][j >> 2] >> ((j & 3) * 8)) & 7u) != (ridx & 7u)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
+            for (int k = 0; k < 4; k++) {
+                uint32_t f = rq[k];
+                while (f) {
+                    const uint32_t bit = f & (0u - f);           // lowest marker byte of this dword (0x80 << 8j)
+                    f ^= bit;
+                    const uint32_t sh = 31u - (uint32_t)__builtin_clz(bit) - 7u;      // 8j
+                    const uint32_t nk = ridx + 1;                // interval that starts after this marker
+                    const uint32_t off = kb + __popc(keep[r][k] & (bit - 1u));
+                    if (nk < im.n_intervals) a.interval_start[im.interval_base + nk] = off;
+                    if (((w[r][k] >> sh) & 7u) != (ridx & 7u)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
                     ridx++;
                 }
-                if (keep[r][j >> 2] & bit) kb++;
+                kb += __popc(keep[r][k]);
             }
+        }
     }
     __syncthreads();
     // ---- LDS -> stream: whole 16-byte quads, bytes at the two ragged ends -------------------------------------
@@ -1198,7 +1208,7 @@ void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t 
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix_k0;
     // ticket counter + per-chunk status words start at zero every run (memsets of >= 256 bytes on the stream)
-    (void)hipMemsetAsync(a.k0_ticket, 0, 256, s);
+    (void)hipMemsetAsync(a.k0_ticket, 0, (((size_t)a.n_images * 4) + 255) & ~(size_t)255, s);
     (void)hipMemsetAsync(a.k0_state, 0, ((size_t)wgs * 8 + 255) & ~(size_t)255, s);
     hipLaunchKernelGGL(k0_unstuff, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
 }
