@@ -27,7 +27,11 @@
 // whole-block Huffman writer: waves per workgroup (they share the lookup tables) and LDS bytes per lane
 // (128-byte block slot + 128-byte stream ring)
 #define JD_W_WAVES 4
-#define JD_LANE_LDS 256u
+#ifndef JD_RING_B
+#define JD_RING_B 128u            // stream ring per lane, bytes (power of two >= 32)
+#endif
+#define JD_RING_PRIME (JD_RING_B / 16u < 4u ? JD_RING_B / 16u : 4u)
+#define JD_LANE_LDS (128u + JD_RING_B)
 
 // unstuff pass: bytes per workgroup
 #define JD_K0_THREADS 256

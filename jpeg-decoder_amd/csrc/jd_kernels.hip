@@ -351,8 +351,9 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wbase = lut_bytes + wv * (64u * JD_LANE_LDS);          // lut_bytes: multiple of 128
     const uint32_t slot_b = wbase + lane * 128u;                         // byte offsets inside dyn_lds
-    const uint32_t ring_b = wbase + 64u * 128u + lane * 128u;
-    const uint32_t rot = (lane & 7u) << 4;
+    const uint32_t ring_b = wbase + 64u * 128u + lane * JD_RING_B;
+    const uint32_t rot = (lane & 7u) << 4;                               // slot swizzle
+    const uint32_t rrot = (lane & (JD_RING_B / 16u - 1u)) << 4;          // ring rotation
 #pragma unroll
     for (int i = 0; i < 8; i++) *reinterpret_cast<uint4*>(dyn_lds + slot_b + i * 16) = make_uint4(0, 0, 0, 0);
     const ImgK ik = load_imgk(im);
@@ -365,17 +366,17 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     const uint32_t g = ((sg.start_bit + 32u - o0) >> 5) + 3u;            // dword (front pad included) that becomes w0
     const uint32_t qbase = (g >> 2) < qmax ? (g >> 2) : qmax;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
+    for (uint32_t k = 0; k < JD_RING_PRIME; k++) {
         const uint4 v = Q[qbase + k < qmax ? qbase + k : qmax];
-        *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((k * 16u + rot) & 127u))) = be32x4(v);
+        *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((k * 16u + rrot) & (JD_RING_B - 1u)))) = be32x4(v);
     }
     // Ring bookkeeping in byte units with the lane's rotation folded in:
     //   rpb = 4 * (dwords taken from the ring) + rot      wqb = 16 * (quads written to the ring) + rot
     // (both monotonic; the ring address of a byte index x is ring_b | (x & 127), ring_b being 128-aligned)
-    uint32_t wqb = 64u + rot;
-    uint32_t rpb = (g & 3u) * 4u + rot;
+    uint32_t wqb = JD_RING_PRIME * 16u + rrot;
+    uint32_t rpb = (g & 3u) * 4u + rrot;
     wave_lds_order();
-    auto ring_at = [&](uint32_t xb) { return lds_u32(ring_b | (xb & 127u)); };
+    auto ring_at = [&](uint32_t xb) { return lds_u32(ring_b | (xb & (JD_RING_B - 1u))); };
     uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 4), nxt = ring_at(rpb + 8);
     rpb += 12;
     int sh = 32 - (int)o0;                                               // window = alignbit(w0, w1, sh), sh in [0,31]
@@ -402,18 +403,18 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     }
     const uint32_t f_src = wbase + (lane >> 3) * 128u + ((part ^ ((lane >> 3) & 7u)) << 4);   // + r * 1024
 
-    auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rot) >> 4); return q < qmax ? q : qmax; };
+    auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rrot) >> 4); return q < qmax ? q : qmax; };
     // The ring word that the next refill needs is read at the top of every symbol step, beside the table
     // lookup (`cand`).  A lane whose read pointer caught up with its write pointer (a block far larger than
     // the boundary top-ups cover) gets one more quad on the spot; rare, so the test is one wave-wide branch.
     auto top_up_now = [&]() {
         if (rpb >= wqb) {
-            if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 127u))) = be32x4(pq0);
-            if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & 127u))) = be32x4(pq1);
+            if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & (JD_RING_B - 1u)))) = be32x4(pq0);
+            if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & (JD_RING_B - 1u)))) = be32x4(pq1);
             wqb += npend * 16u; npend = 0;
             if (rpb >= wqb) {
                 const uint4 v = Q[quad_index(wqb)];
-                *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 127u))) = be32x4(v);
+                *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & (JD_RING_B - 1u)))) = be32x4(v);
                 wqb += 16u;
             }
         }
@@ -429,13 +430,12 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 
 #pragma unroll 1
     for (uint32_t b = 0; b < nmax; b++) {
-        // ---- ring top-up (commit last boundary's loads, request the next ones) -----------------------
-        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 127u))) = be32x4(pq0);
-        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & 127u))) = be32x4(pq1);
-        wqb += npend * 16u;
+        // ---- ring top-up: request up to two quads now; they are committed to the ring at the END of this block
+        // step, just before its block stores are issued.  (Committed at the next boundary instead, the wait for
+        // them -- vmcnt counts in order -- would also wait for those stores to reach memory, every step.)
         {
-            const uint32_t used = (wqb >> 4) - (rpb >> 4);       // quads holding unread data (<= 8); rot < 16 cancels
-            const uint32_t freeq = 8u - used;
+            const uint32_t used = (wqb >> 4) - (rpb >> 4);       // quads holding unread data (<= 8); rrot cancels
+            const uint32_t freeq = JD_RING_B / 16u - used;
             npend = b < sg.nblk ? (freeq < 2u ? freeq : 2u) : 0u;
             if (npend >= 1) pq0 = Q[quad_index(wqb)];
             if (npend >= 2) pq1 = Q[quad_index(wqb + 16u)];
@@ -474,6 +474,9 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
                 *reinterpret_cast<int16_t*>(dyn_lds + slot_b + ((z * 2u - 2u) ^ rot)) = (int16_t)extend_bits(win, total, size);
         }
         if (b < sg.nblk && z > 64u && zlast != 63u) err |= JD_ST_COEF;      // run walked past coefficient 63
+        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & (JD_RING_B - 1u)))) = be32x4(pq0);
+        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & (JD_RING_B - 1u)))) = be32x4(pq1);
+        wqb += npend * 16u; npend = 0;
         wave_lds_order();
         // ---- flush: 8 lanes move one 128-byte block; 8 blocks per pass -----------------------------------
 #pragma unroll
@@ -490,7 +493,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
         if (bad) err |= JD_ST_HUFF;
         // bit position = 32 * (dwords consumed before w0) + bits of w0 consumed; w0 is ring dword (rp - 3) and
         // the front pad holds 4 dwords
-        const uint32_t rp = (rpb - rot) >> 2;
+        const uint32_t rp = (rpb - rrot) >> 2;
         const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - (uint32_t)sh);
         if (pos > sg.end_bit) err |= JD_ST_TRUNC;                 // ran past the segment: data ended early
     }
