@@ -165,9 +165,9 @@ struct jd_batch {
     uint8_t* d_ecs_own = nullptr; uint8_t* d_rgb_own = nullptr; uint8_t* d_stream = nullptr;
     int16_t* d_coef = nullptr; uint16_t* d_lut = nullptr;
     uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
-    unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; uint4* d_sync_tot = nullptr;
-    uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_tile = nullptr;
-    std::vector<uint32_t> pre_k0, pre_iv, pre_sync, pre_tile;
+    unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; JdSubPfx* d_subpfx = nullptr; uint4* d_sync_tot = nullptr;
+    uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr;
+    std::vector<uint32_t> pre_k0, pre_iv, pre_sync, pre_wr, pre_tile;
     std::vector<std::pair<size_t, size_t>> clear_ranges;   // coefficient ranges (int16 offset, count) that need zero-fill
     size_t rgb_own_bytes = 0, stream_bytes = 0, coef_elems = 0, workspace = 0;
     uint32_t max_lut_bytes = 0, max_bpm = 1;
@@ -196,14 +196,14 @@ JdKernelArgs kernel_args(const jd_batch* b) {
     JdKernelArgs a;
     a.imgs = b->d_img; a.n_images = b->n; a.prefix = nullptr; a.stream = b->d_stream; a.coef = b->d_coef;
     a.lut = b->d_lut; a.status = b->d_status; a.stream_len = b->d_stream_len; a.interval_start = b->d_interval;
-    a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
+    a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.subpfx = b->d_subpfx; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
     return a;
 }
 
 // recompute the per-kernel workgroup prefixes from the current ECS lengths and push descriptors
 int refresh(jd_batch* b, hipStream_t s) {
     const int n = b->n;
-    b->pre_k0.assign(n + 1, 0); b->pre_iv.assign(n + 1, 0); b->pre_sync.assign(n + 1, 0); b->pre_tile.assign(n + 1, 0);
+    b->pre_k0.assign(n + 1, 0); b->pre_iv.assign(n + 1, 0); b->pre_sync.assign(n + 1, 0); b->pre_wr.assign(n + 1, 0); b->pre_tile.assign(n + 1, 0);
     for (int i = 0; i < n; i++) {
         JdImg& im = b->img[i];
         const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
@@ -213,6 +213,7 @@ int refresh(jd_batch* b, hipStream_t s) {
         b->pre_k0[i + 1] = b->pre_k0[i] + im.n_k0_chunks;
         b->pre_iv[i + 1] = b->pre_iv[i] + (im.restart_interval ? (im.n_intervals + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES) : 0);
         b->pre_sync[i + 1] = b->pre_sync[i] + nsw;
+        b->pre_wr[i + 1] = b->pre_wr[i] + (nsw * JD_SYNC_WG + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
         b->pre_tile[i + 1] = b->pre_tile[i] + im.n_tiles;
     }
     // Both Huffman writers store whole blocks (zeros included): no coefficient range needs a zero-fill pass.
@@ -222,6 +223,7 @@ int refresh(jd_batch* b, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(b->d_pre_k0, b->pre_k0.data(), pb, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_pre_iv, b->pre_iv.data(), pb, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_pre_sync, b->pre_sync.data(), pb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_pre_wr, b->pre_wr.data(), pb, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(b->d_pre_tile, b->pre_tile.data(), pb, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));          // the host vectors may be rewritten by the next refresh
     b->dirty = false;
@@ -256,7 +258,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
         }
         break;
     case ST_HUFF_WRITE:
-        jdk_launch_write_subseq(a, b->d_pre_sync, b->pre_sync[n], b->max_lut_bytes, s);
+        jdk_launch_write_subseq(a, b->d_pre_wr, b->pre_wr[n], b->max_lut_bytes, s);
         break;
     case ST_IDCT_COLOUR:
         jdk_launch_idct_colour(a, b->d_pre_tile, b->pre_tile[n], b->max_bpm, b->K, s);
@@ -354,7 +356,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         im.row_stride = (uint32_t)f.width * 3;
         im.ecs_len = 0;
     }
-    if (b->max_lut_bytes > 160 * 1024 - JD_W_WAVES * 64 * JD_LANE_LDS - 1024) { delete b; return JD_E_TABLE; }
+    if (b->max_lut_bytes > 160 * 1024 - JD_W_WAVES * JD_WAVE_LDS - 1024) { delete b; return JD_E_TABLE; }
     b->rgb_own_bytes = rgb_own; b->stream_bytes = stream; b->coef_elems = coef;
 
     size_t tot = 0;
@@ -373,10 +375,12 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
     A(dev_alloc(&b->d_k0, (size_t)k0c + 32, &tot));
     A(dev_alloc(&b->d_ticket, (size_t)n_images + 64, &tot));
     A(dev_alloc(&b->d_sub, (size_t)subb, &tot));
+    A(dev_alloc(&b->d_subpfx, (size_t)subb, &tot));
     A(dev_alloc(&b->d_sync_tot, (size_t)swb, &tot));
     A(dev_alloc(&b->d_pre_k0, (size_t)n_images + 1, &tot));
     A(dev_alloc(&b->d_pre_iv, (size_t)n_images + 1, &tot));
     A(dev_alloc(&b->d_pre_sync, (size_t)n_images + 1, &tot));
+    A(dev_alloc(&b->d_pre_wr, (size_t)n_images + 1, &tot));
     A(dev_alloc(&b->d_pre_tile, (size_t)n_images + 1, &tot));
     if (rc == JD_OK && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) rc = JD_E_HIP;
     if (rc == JD_OK && hipMemcpy(b->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) rc = JD_E_HIP;
@@ -396,7 +400,7 @@ extern "C" void jd_batch_destroy(jd_batch* b) {
     (void)hipSetDevice(b->device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     void* ptrs[] = { b->d_img, b->d_ecs_own, b->d_rgb_own, b->d_stream, b->d_coef, b->d_lut, b->d_status, b->d_stream_len,
-                     b->d_interval, b->d_changed, b->d_k0, b->d_ticket, b->d_sub, b->d_sync_tot, b->d_pre_k0, b->d_pre_iv, b->d_pre_sync,
+                     b->d_interval, b->d_changed, b->d_k0, b->d_ticket, b->d_sub, b->d_subpfx, b->d_sync_tot, b->d_pre_k0, b->d_pre_iv, b->d_pre_sync, b->d_pre_wr,
                      b->d_pre_tile };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : b->events) (void)hipEventDestroy(e);

@@ -24,14 +24,10 @@
 #define JD_SYNC_WARM 3
 #define JD_SYNC_OWN (JD_SYNC_WG - JD_SYNC_WARM)
 
-// whole-block Huffman writer: waves per workgroup (they share the lookup tables) and LDS bytes per lane
-// (128-byte block slot + 128-byte stream ring)
-#define JD_W_WAVES 4
-#ifndef JD_RING_B
-#define JD_RING_B 128u            // stream ring per lane, bytes (power of two >= 32)
-#endif
-#define JD_RING_PRIME (JD_RING_B / 16u < 4u ? JD_RING_B / 16u : 4u)
-#define JD_LANE_LDS (128u + JD_RING_B)
+// whole-block Huffman writer: waves per workgroup (they share the lookup tables) and LDS bytes per wave
+// (per lane a 64-byte half-block slot + a 64-byte stream ring, plus 256 bytes of dump words)
+#define JD_W_WAVES 8
+#define JD_WAVE_LDS (64u * 128u + 256u)
 
 // unstuff pass: bytes per workgroup
 #define JD_K0_THREADS 256
@@ -98,6 +94,8 @@ struct JdSub {
 // packed state: [7:0] bit offset past the sub-sequence start, [15:8] block-in-MCU, [23:16] zig-zag index,
 // bit 31 = valid
 #define JD_STATE_VALID 0x80000000u
+// exclusive prefix of a sub-sequence inside its sync workgroup (block starts, DC-difference sums)
+struct JdSubPfx { uint32_t blk_off; int32_t dcp[3]; };
 
 struct JdKernelArgs {
     const JdImg* imgs;
@@ -112,6 +110,7 @@ struct JdKernelArgs {
     unsigned long long* k0_state; // per K0 chunk: look-back status word (jd_kernels.hip)
     uint32_t* k0_ticket;         // per image: next chunk to hand out
     JdSub* sub;
+    JdSubPfx* subpfx;
     uint4* sync_tot;             // per sync workgroup: (block starts, dc0, dc1, dc2) totals -> exclusive prefix after spine
     uint32_t* changed;           // sync: set when a workgroup's exit state changed
 };

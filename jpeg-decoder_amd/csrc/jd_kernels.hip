@@ -307,15 +307,17 @@ __device__ __forceinline__ int extend_bits(uint32_t win, uint32_t total, uint32_
 // predictors are known -- a restart interval (DC predictors reset, data byte aligned), or the blocks that
 // start inside one sub-sequence of the self-synchronising pass.  Each wave walks its 64 segments
 // BLOCK-SYNCHRONOUSLY: every lane finishes block b of its segment before any lane starts b+1.
-//   * each lane assembles its block in a private 128-byte LDS slot, so the 64 finished blocks leave as full
-//     128-byte lines (8 lanes x 16 B per block) and zeros never need a separate fill pass;
-//   * each lane reads the stream through a private 128-byte LDS ring topped up at the block boundaries with
-//     16-byte loads issued one block-step ahead; four stream dwords are held in registers and the ring word
-//     that replaces the oldest is requested one refill before it is needed, so the symbol loop's only
-//     dependent LDS access is the table lookup;
+//   * a block goes out in two halves (coefficients 0-31, then 32-63): each lane assembles a half in a private
+//     64-byte LDS slot and the wave stores the 64 finished halves as 64-byte runs (4 lanes x 16 B each), zeros
+//     included, so no fill pass is needed.  Halving the slot is what lets 16 waves fit on a CU; the symbol loop
+//     is bound by how fast ONE wave can issue (about 600 cycles per step measured at 2 waves per SIMD);
+//   * each lane reads the stream through a private 64-byte LDS ring topped up at both half-block boundaries
+//     with 16-byte loads requested one half-step ahead; three stream dwords are held in registers and the ring
+//     word that replaces the oldest is read beside the table lookup, so the symbol loop's only dependent LDS
+//     access is the table lookup;
 //   * JD_W_WAVES waves share one copy of the lookup tables but are otherwise independent (no workgroup
-//     barrier after the table load): LDS is 256 B per lane + the tables, two workgroups per CU.
-// Slot and ring are swizzled by lane (16-byte chunk index rotated / xor-ed with lane & 7) instead of padded.
+//     barrier after the table load): LDS is 128 B per lane + 256 B per wave + the tables, two workgroups per CU.
+// Slot and ring are swizzled by lane (16-byte chunk index rotated / xor-ed with lane & 3) instead of padded.
 
 struct Segment {
     uint32_t start_bit;      // first bit of the first block
@@ -349,13 +351,13 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
                                                const Segment& sg, uint32_t slen, uint32_t err) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t wbase = lut_bytes + wv * (64u * JD_LANE_LDS);          // lut_bytes: multiple of 128
-    const uint32_t slot_b = wbase + lane * 128u;                         // byte offsets inside dyn_lds
-    const uint32_t ring_b = wbase + 64u * 128u + lane * JD_RING_B;
-    const uint32_t rot = (lane & 7u) << 4;                               // slot swizzle
-    const uint32_t rrot = (lane & (JD_RING_B / 16u - 1u)) << 4;          // ring rotation
+    const uint32_t wbase = lut_bytes + wv * JD_WAVE_LDS;                 // lut_bytes: multiple of 128
+    const uint32_t slot_b = wbase + lane * 64u;                          // byte offsets inside dyn_lds
+    const uint32_t ring_b = wbase + 4096u + lane * 64u;
+    const uint32_t dump_b = wbase + 8192u + lane * 4u;                   // where coefficient-less symbols "store"
+    const uint32_t rot = (lane & 3u) << 4;                               // slot swizzle and ring rotation (4 chunks each)
 #pragma unroll
-    for (int i = 0; i < 8; i++) *reinterpret_cast<uint4*>(dyn_lds + slot_b + i * 16) = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(dyn_lds + slot_b + i * 16) = make_uint4(0, 0, 0, 0);
     const ImgK ik = load_imgk(im);
     const uint32_t bpm = ik.bpm;
 
@@ -366,21 +368,21 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     const uint32_t g = ((sg.start_bit + 32u - o0) >> 5) + 3u;            // dword (front pad included) that becomes w0
     const uint32_t qbase = (g >> 2) < qmax ? (g >> 2) : qmax;
 #pragma unroll
-    for (uint32_t k = 0; k < JD_RING_PRIME; k++) {
+    for (uint32_t k = 0; k < 4; k++) {
         const uint4 v = Q[qbase + k < qmax ? qbase + k : qmax];
-        *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((k * 16u + rrot) & (JD_RING_B - 1u)))) = be32x4(v);
+        *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((k * 16u + rot) & 63u))) = be32x4(v);
     }
     // Ring bookkeeping in byte units with the lane's rotation folded in:
     //   rpb = 4 * (dwords taken from the ring) + rot      wqb = 16 * (quads written to the ring) + rot
-    // (both monotonic; the ring address of a byte index x is ring_b | (x & 127), ring_b being 128-aligned)
-    uint32_t wqb = JD_RING_PRIME * 16u + rrot;
-    uint32_t rpb = (g & 3u) * 4u + rrot;
+    // (both monotonic; the ring address of a byte index x is ring_b | (x & 63), ring_b being 64-aligned)
+    uint32_t wqb = 64u + rot;
+    uint32_t rpb = (g & 3u) * 4u + rot;
     wave_lds_order();
-    auto ring_at = [&](uint32_t xb) { return lds_u32(ring_b | (xb & (JD_RING_B - 1u))); };
+    auto ring_at = [&](uint32_t xb) { return lds_u32(ring_b | (xb & 63u)); };
     uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 4), nxt = ring_at(rpb + 8);
     rpb += 12;
     int sh = 32 - (int)o0;                                               // window = alignbit(w0, w1, sh), sh in [0,31]
-    uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;                       // quads in flight (requested last boundary)
+    uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;                       // quads requested, not yet in the ring
     uint32_t npend = 0;
 
     int p0 = sg.p0, p1 = sg.p1, p2 = sg.p2;
@@ -391,30 +393,42 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nmax, d, 64); nmax = t > nmax ? t : nmax; }
 
-    // flush plan: in pass r lanes 8t'..8t'+7 move the block of lane t = 8r + (lane >> 3), 16 bytes each
-    const uint32_t part = lane & 7u;
-    uint32_t f_nblk[8];
-    int16_t* f_dst[8];
+    // flush plan (one half block = 64 bytes): in pass r lanes 4t'..4t'+3 move the half of lane t = 16r + (lane >> 2)
+    const uint32_t part = lane & 3u;
+    uint32_t f_nblk[4];
+    int16_t* f_dst[4];
 #pragma unroll
-    for (uint32_t r = 0; r < 8; r++) {
-        const uint32_t t = r * 8u + (lane >> 3);
+    for (uint32_t r = 0; r < 4; r++) {
+        const uint32_t t = r * 16u + (lane >> 2);
         f_nblk[r] = __shfl(sg.nblk, t, 64);
         f_dst[r] = gbase + (uint64_t)__shfl(sg.blk0, t, 64) * 64u + part * 8u;
     }
-    const uint32_t f_src = wbase + (lane >> 3) * 128u + ((part ^ ((lane >> 3) & 7u)) << 4);   // + r * 1024
+    const uint32_t f_src = wbase + (lane >> 2) * 64u + ((part ^ ((lane >> 2) & 3u)) << 4);   // + r * 1024
 
-    auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rrot) >> 4); return q < qmax ? q : qmax; };
+    auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rot) >> 4); return q < qmax ? q : qmax; };
+    auto request = [&](bool want) {                                      // up to two quads into the free part of the ring
+        const uint32_t used = (wqb >> 4) - (rpb >> 4);                   // quads holding unread data (<= 4); rot cancels
+        const uint32_t freeq = 4u - used;
+        npend = want ? (freeq < 2u ? freeq : 2u) : 0u;
+        if (npend >= 1) pq0 = Q[quad_index(wqb)];
+        if (npend >= 2) pq1 = Q[quad_index(wqb + 16u)];
+    };
+    // Requested quads are committed just before the block stores of the same half step are issued: vmcnt counts in
+    // order, so a wait placed after those stores would also wait for them to reach memory.
+    auto commit = [&]() {
+        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 63u))) = be32x4(pq0);
+        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & 63u))) = be32x4(pq1);
+        wqb += npend * 16u; npend = 0;
+    };
     // The ring word that the next refill needs is read at the top of every symbol step, beside the table
-    // lookup (`cand`).  A lane whose read pointer caught up with its write pointer (a block far larger than
-    // the boundary top-ups cover) gets one more quad on the spot; rare, so the test is one wave-wide branch.
+    // lookup (`cand`).  A lane whose read pointer caught up with its write pointer gets one more quad on the
+    // spot; rare, so the test is one wave-wide branch.
     auto top_up_now = [&]() {
         if (rpb >= wqb) {
-            if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & (JD_RING_B - 1u)))) = be32x4(pq0);
-            if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & (JD_RING_B - 1u)))) = be32x4(pq1);
-            wqb += npend * 16u; npend = 0;
+            commit();
             if (rpb >= wqb) {
                 const uint4 v = Q[quad_index(wqb)];
-                *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & (JD_RING_B - 1u)))) = be32x4(v);
+                *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 63u))) = be32x4(v);
                 wqb += 16u;
             }
         }
@@ -427,65 +441,80 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
         w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
         sh += r ? 32 : 0; rpb += r ? 4u : 0u;
     };
+    auto flush = [&](uint32_t b, uint32_t half) {                        // 4 lanes move one 64-byte half block
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            uint4* src = reinterpret_cast<uint4*>(dyn_lds + f_src + r * 1024u);
+            const uint4 v = *src;
+            *src = make_uint4(0, 0, 0, 0);
+            if (b < f_nblk[r]) *reinterpret_cast<uint4*>(f_dst[r] + (uint64_t)b * 64u + half * 32u) = v;
+        }
+    };
 
 #pragma unroll 1
     for (uint32_t b = 0; b < nmax; b++) {
-        // ---- ring top-up: request up to two quads now; they are committed to the ring at the END of this block
-        // step, just before its block stores are issued.  (Committed at the next boundary instead, the wait for
-        // them -- vmcnt counts in order -- would also wait for those stores to reach memory, every step.)
-        {
-            const uint32_t used = (wqb >> 4) - (rpb >> 4);       // quads holding unread data (<= 8); rrot cancels
-            const uint32_t freeq = JD_RING_B / 16u - used;
-            npend = b < sg.nblk ? (freeq < 2u ? freeq : 2u) : 0u;
-            if (npend >= 1) pq0 = Q[quad_index(wqb)];
-            if (npend >= 2) pq1 = Q[quad_index(wqb + 16u)];
-        }
+        request(b < sg.nblk);
         wave_lds_order();
         // ---- tables of this block's component -----------------------------------------------------------
         const uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;
         const uint32_t dcb = sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u;      // byte offsets into the LUT
         const uint32_t acb = sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
-        uint32_t z = 64, zlast = 63;
+        uint32_t z = 64, zlast = 63, size = 0;
+        int v = 0;
         if (b < sg.nblk) {
             // DC: category, magnitude bits, EXTEND, prediction (main.go:188-201)
             if (__builtin_amdgcn_ballot_w64(rpb >= wqb)) top_up_now();
             const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
             const uint32_t e = lut_lookup(dcb, win, bad);
-            const uint32_t total = e & 31u, size = (e >> 5) & 15u;
-            const int diff = extend_bits(win, total, size);
+            const uint32_t total = e & 31u;
+            const int diff = extend_bits(win, total, (e >> 5) & 15u);
             advance(total, cand);
             const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
             p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
-            *reinterpret_cast<int16_t*>(dyn_lds + slot_b + rot) = (int16_t)pred;   // coefficient 0: chunk 0 ^ (lane & 7)
+            *reinterpret_cast<int16_t*>(dyn_lds + slot_b + rot) = (int16_t)pred;   // coefficient 0: chunk 0 ^ (lane & 3)
             z = 1;
         }
-        // ---- AC: run/size symbols until every lane's block is complete (main.go:204-239) ----------------
-        while (z < 64u) {                                         // divergent loop: finished lanes drop out
+        // ---- AC, first half: symbols until every lane has passed coefficient 31 (main.go:204-239) ----------
+        while (z < 32u) {                                         // divergent loop: finished lanes drop out
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
             const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
             const uint32_t e = lut_lookup(acb, win, bad);
-            const uint32_t total = e & 31u, size = (e >> 5) & 15u;
-            zlast = (e >> 9) & 63u;
+            const uint32_t total = e & 31u;
+            size = (e >> 5) & 15u; zlast = (e >> 9) & 63u;
+            v = extend_bits(win, total, size);
             advance(total, cand);
             z += zlast + 1u;
-            if (size != 0 && z <= 64u)
-                *reinterpret_cast<int16_t*>(dyn_lds + slot_b + ((z * 2u - 2u) ^ rot)) = (int16_t)extend_bits(win, total, size);
+            // a symbol without a coefficient (EOB, ZRL) or one that lands in the other half stores to a dump word
+            const uint32_t at = (size != 0 && z <= 32u) ? slot_b + ((z * 2u - 2u) ^ rot) : dump_b;
+            *reinterpret_cast<int16_t*>(dyn_lds + at) = (int16_t)v;
+        }
+        commit();
+        wave_lds_order();
+        flush(b, 0);
+        wave_lds_order();
+        request(b < sg.nblk && z < 64u);
+        // the symbol that crossed into the second half left its coefficient for now
+        if (b < sg.nblk && size != 0 && z > 32u && z <= 64u) *reinterpret_cast<int16_t*>(dyn_lds + slot_b + ((z * 2u - 66u) ^ rot)) = (int16_t)v;
+        // ---- AC, second half ----------------------------------------------------------------------------------
+        while (z < 64u) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
+            const uint32_t cand = ring_at(rpb);
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
+            const uint32_t e = lut_lookup(acb, win, bad);
+            const uint32_t total = e & 31u;
+            size = (e >> 5) & 15u; zlast = (e >> 9) & 63u;
+            v = extend_bits(win, total, size);
+            advance(total, cand);
+            z += zlast + 1u;
+            const uint32_t at = (size != 0 && z <= 64u) ? slot_b + ((z * 2u - 66u) ^ rot) : dump_b;
+            *reinterpret_cast<int16_t*>(dyn_lds + at) = (int16_t)v;
         }
         if (b < sg.nblk && z > 64u && zlast != 63u) err |= JD_ST_COEF;      // run walked past coefficient 63
-        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & (JD_RING_B - 1u)))) = be32x4(pq0);
-        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & (JD_RING_B - 1u)))) = be32x4(pq1);
-        wqb += npend * 16u; npend = 0;
+        commit();
         wave_lds_order();
-        // ---- flush: 8 lanes move one 128-byte block; 8 blocks per pass -----------------------------------
-#pragma unroll
-        for (uint32_t r = 0; r < 8; r++) {
-            uint4* src = reinterpret_cast<uint4*>(dyn_lds + f_src + r * 1024u);
-            const uint4 v = *src;
-            *src = make_uint4(0, 0, 0, 0);
-            if (b < f_nblk[r]) *reinterpret_cast<uint4*>(f_dst[r] + (uint64_t)b * 64u) = v;
-        }
+        flush(b, 1);
         wave_lds_order();
         c = (c + 1u == bpm) ? 0u : c + 1u;
     }
@@ -493,7 +522,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
         if (bad) err |= JD_ST_HUFF;
         // bit position = 32 * (dwords consumed before w0) + bits of w0 consumed; w0 is ring dword (rp - 3) and
         // the front pad holds 4 dwords
-        const uint32_t rp = (rpb - rrot) >> 2;
+        const uint32_t rp = (rpb - rot) >> 2;
         const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - (uint32_t)sh);
         if (pos > sg.end_bit) err |= JD_ST_TRUNC;                 // ran past the segment: data ended early
     }
@@ -536,7 +565,6 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelAr
 // the spine scan turns into block indices and DC predictors for the write pass (the DC prefix scan).
 #define JD_SPEC_RING_DW 16u                                   // ring depth in dwords (4 quads)
 #define JD_SPEC_RING_BYTES (JD_SPEC_RING_DW * 256u)           // per wave: [dword][lane]
-static_assert(JD_SYNC_WG == 64 * JD_W_WAVES, "the write pass reuses the sync pass's workgroup prefix");
 
 // LDS map of k1_sync (byte offsets in dyn_lds)
 #define JD_SY_RINGS 0u
@@ -717,11 +745,14 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     }
     if (owned) gsub[s] = rec;
     // workgroup totals for the spine scan
+    // ... and every owned lane's exclusive prefix inside the workgroup, for the write pass
     uint32_t t0, t1, t2, t3;
-    block_excl_scan(owned ? rec.nstart : 0u, tmp, t0);
-    block_excl_scan(owned ? (uint32_t)rec.dc[0] : 0u, tmp, t1);
-    block_excl_scan(owned ? (uint32_t)rec.dc[1] : 0u, tmp, t2);
-    block_excl_scan(owned ? (uint32_t)rec.dc[2] : 0u, tmp, t3);
+    JdSubPfx pf;
+    pf.blk_off = block_excl_scan(owned ? rec.nstart : 0u, tmp, t0);
+    pf.dcp[0] = (int)block_excl_scan(owned ? (uint32_t)rec.dc[0] : 0u, tmp, t1);
+    pf.dcp[1] = (int)block_excl_scan(owned ? (uint32_t)rec.dc[1] : 0u, tmp, t2);
+    pf.dcp[2] = (int)block_excl_scan(owned ? (uint32_t)rec.dc[2] : 0u, tmp, t3);
+    if (owned) a.subpfx[im.subseq_base + s] = pf;
     if (threadIdx.x == 0) a.sync_tot[im.sync_wg_base + lw] = make_uint4(t0, t1, t2, t3);
     const uint32_t rem = nsub - lw * JD_SYNC_OWN;
     const uint32_t last = JD_SYNC_WARM + (rem < JD_SYNC_OWN ? rem : JD_SYNC_OWN) - 1u;
@@ -754,39 +785,40 @@ __global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
 }
 
 // ---- no-DRI path, pass 2: segment = the blocks that start inside one sub-sequence ------------------------
+// Lane L of the image handles owned lane L % JD_SYNC_WG of sync workgroup L / JD_SYNC_WG.
 __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs a, uint32_t lut_bytes) {
-    __shared__ uint32_t tmp[16];
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
-    if (lw * JD_SYNC_OWN >= nsub) return;
+    const uint32_t L = lw * (64u * JD_W_WAVES) + threadIdx.x;
+    const uint32_t swg = L / JD_SYNC_WG, sl = L % JD_SYNC_WG;
+    if ((lw * (64u * JD_W_WAVES) / JD_SYNC_WG) * JD_SYNC_OWN >= nsub) return;   // whole workgroup past the stream
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.lut_off, im.lut_len);
-    const uint32_t s = lw * JD_SYNC_OWN + threadIdx.x;          // same partition as the sync pass (last lanes idle)
-    const bool active = threadIdx.x < JD_SYNC_OWN && s < nsub;
-    JdSub rec; rec.entry = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0;
-    if (active) rec = a.sub[im.subseq_base + s];
-    const uint4 base = a.sync_tot[im.sync_wg_base + lw];
-    uint32_t t;
-    const uint32_t blk0 = base.x + block_excl_scan(rec.nstart, tmp, t);
-    Segment sg;
-    sg.p0 = (int)(base.y + block_excl_scan((uint32_t)rec.dc[0], tmp, t));
-    sg.p1 = (int)(base.z + block_excl_scan((uint32_t)rec.dc[1], tmp, t));
-    sg.p2 = (int)(base.w + block_excl_scan((uint32_t)rec.dc[2], tmp, t));
-    const uint32_t total_blocks = im.n_mcus * im.bpm;
+    const uint32_t s = swg * JD_SYNC_OWN + sl;
+    const bool active = sl < JD_SYNC_OWN && s < nsub && swg < im.n_sync_wg;
+    Segment sg; sg.start_bit = 0; sg.end_bit = sbits; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
     uint32_t err = 0;
-    sg.start_bit = s * JD_SUBSEQ_BITS + rec.first; sg.end_bit = sbits; sg.blk0 = blk0;
-    sg.nblk = blk0 < total_blocks ? (rec.nstart < total_blocks - blk0 ? rec.nstart : total_blocks - blk0) : 0u;
-    if (sg.nblk) {
-        // consistency of the scan with the sub-sequence's own state: the first block that starts here must be
-        // the block-in-MCU the entry state implies
-        const uint32_t c = (rec.entry >> 8) & 0xFFu, z = (rec.entry >> 16) & 0x7Fu;
-        const uint32_t cf = z == 0 ? c : (c + 1u == im.bpm ? 0u : c + 1u);
-        if (blk0 % im.bpm != cf) { err = JD_ST_SYNC; sg.nblk = 0; }
+    if (active) {
+        const JdSub rec = a.sub[im.subseq_base + s];
+        const JdSubPfx pf = a.subpfx[im.subseq_base + s];
+        const uint4 base = a.sync_tot[im.sync_wg_base + swg];
+        const uint32_t total_blocks = im.n_mcus * im.bpm;
+        const uint32_t blk0 = base.x + pf.blk_off;
+        sg.p0 = (int)base.y + pf.dcp[0]; sg.p1 = (int)base.z + pf.dcp[1]; sg.p2 = (int)base.w + pf.dcp[2];
+        sg.start_bit = s * JD_SUBSEQ_BITS + rec.first; sg.blk0 = blk0;
+        sg.nblk = blk0 < total_blocks ? (rec.nstart < total_blocks - blk0 ? rec.nstart : total_blocks - blk0) : 0u;
+        if (sg.nblk) {
+            // consistency of the scan with the sub-sequence's own state: the first block that starts here must
+            // be the block-in-MCU the entry state implies
+            const uint32_t c = (rec.entry >> 8) & 0xFFu, z = (rec.entry >> 16) & 0x7Fu;
+            const uint32_t cf = z == 0 ? c : (c + 1u == im.bpm ? 0u : c + 1u);
+            if (blk0 % im.bpm != cf) { err = JD_ST_SYNC; sg.nblk = 0; }
+        }
+        if (!sg.nblk) { sg.start_bit = 0; sg.blk0 = 0; }
     }
-    if (!sg.nblk) { sg.start_bit = 0; sg.blk0 = 0; }
     write_segments(a, im, img, lut_bytes, sg, slen, err);
 }
 
@@ -1220,7 +1252,7 @@ void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint3
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
-    const uint32_t lds = lb + JD_W_WAVES * 64u * JD_LANE_LDS;
+    const uint32_t lds = lb + JD_W_WAVES * JD_WAVE_LDS;
     if (lds > 64u * 1024u)                                       // > 64 KiB of dynamic LDS needs the attribute (per device)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_intervals), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
@@ -1243,7 +1275,7 @@ void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, ui
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
-    const uint32_t lds = lb + JD_W_WAVES * 64u * JD_LANE_LDS;
+    const uint32_t lds = lb + JD_W_WAVES * JD_WAVE_LDS;
     if (lds > 64u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_subseq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k1_write_subseq, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
