@@ -58,9 +58,9 @@ def cpu_baseline(workload, quality, detail):
     import jpeg_decoder_amd as jd
     if workload in ("c3", "c4"):
         w = h = 8192
-        n = 3
+        n = 6
     else:
-        w, h, n = 1920, 1080, 6
+        w, h, n = 1920, 1080, 120
     px, t_hot, t_wall = 0, 0.0, 0.0
     for i in range(n):
         data = jd.SynthImage(w, h, 2, 2, 3, quality=quality, seed=i, detail=detail).encode(0)
@@ -103,7 +103,7 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    batch = args.batch or {"c3": 4, "c4": 4, "c5": 256}[args.workload]
+    batch = args.batch or {"c3": 8, "c4": 4, "c5": 256}[args.workload]
     w, h, ri, files, distinct = make_images(args.workload, batch, rank, args.quality, args.detail)
 
     jd.init([local_rank])
@@ -152,14 +152,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    STAGE_KERNEL = {"unstuff": "k0_scatter", "huffman_intervals": "k1_write_intervals", "huffman_sync": "k1_sync",
-                    "huffman_write": "k1_write_subseq", "idct_colour": "k2_idct_colour"}
+    STAGE_KERNEL = {"unstuff": "k0_unstuff", "huffman_intervals": "k1_write_intervals", "huffman_sync": "k1_sync",
+                    "huffman_write": "k1_write_subseq", "idct_colour": "k2_mcu_lanes"}
 
     def recorded_traffic(kernel):
-        """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_b_traffic.json), if they were
+        """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_c_traffic.json), if they were
         taken on this workload and batch; PMC counters cannot be read from inside this process."""
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_b_traffic.json")))["workloads"][args.workload]
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")))["workloads"][args.workload]
             if rec["batch"] != batch:
                 return None
             return rec["kernels"][kernel]["hbm_bytes_per_launch"]
@@ -187,6 +187,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(STAGE_KERNEL.get(dom, dom)),
                          "launch_us": round(stages[dom], 1), "algorithmic_bytes_per_launch": alg_bytes,
+                         "whole_path_frac": round(alg_bytes / (sum(stages.values()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                          "stage_us": {k: round(v, 1) for k, v in stages.items()}, "runs_averaged": nruns},
         }
         if world == 1 and not args.no_cpu_baseline:
