@@ -170,7 +170,7 @@ struct jd_batch {
     std::vector<uint32_t> pre_k0, pre_iv, pre_sync, pre_wr, pre_tile;
     std::vector<std::pair<size_t, size_t>> clear_ranges;   // coefficient ranges (int16 offset, count) that need zero-fill
     size_t rgb_own_bytes = 0, stream_bytes = 0, coef_elems = 0, workspace = 0;
-    uint32_t max_lut_bytes = 0, max_bpm = 1;
+    uint32_t max_lut_bytes = 0, max_w_bytes = 0, max_bpm = 1;
     bool dirty = true, ran = false, any_dri = false, any_nodri = false;
     hipStream_t stream = nullptr, last_stream = nullptr;
     JdIdctConst K;
@@ -247,7 +247,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
         jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[n], s);
         break;
     case ST_HUFF_DRI:
-        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[n], b->max_lut_bytes, s);
+        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[n], b->max_w_bytes, s);
         break;
     case ST_HUFF_SYNC:
         if (b->pre_sync[n]) {
@@ -258,7 +258,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
         }
         break;
     case ST_HUFF_WRITE:
-        jdk_launch_write_subseq(a, b->d_pre_wr, b->pre_wr[n], b->max_lut_bytes, s);
+        jdk_launch_write_subseq(a, b->d_pre_wr, b->pre_wr[n], b->max_w_bytes, s);
         break;
     case ST_IDCT_COLOUR:
         jdk_launch_idct_colour(a, b->d_pre_tile, b->pre_tile[n], b->max_bpm, b->K, s);
@@ -312,8 +312,9 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         if (f.restart_interval) b->any_dri = true; else b->any_nodri = true;
         // table set: per component (td, ta); identical (class,id) pairs share one packed table
         std::string key;
-        std::vector<uint16_t> set, sset;                          // writer tables / sync-pass twin (same layout)
-        std::map<int, uint32_t> placed;                           // class*4+id -> entry offset in set
+        std::vector<uint16_t> set, sset;                          // single-symbol tables / sync-pass twin (same layout)
+        std::vector<uint32_t> wset;                               // writer tables (32-bit entries)
+        std::map<int, uint32_t> placed, wplaced;                  // class*4+id -> entry offset in set / wset
         for (int c = 0; c < f.ncomp; c++) {
             for (int cls = 0; cls < 2; cls++) {
                 const int id = cls ? f.comp[c].ta : f.comp[c].td;
@@ -325,22 +326,30 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
                     if (cls == 0) jd_pack_lut(h.bits, h.vals, h.nvals, true, sset);
                     else jd_pack_lut_multi(h.bits, h.vals, h.nvals, sset);
                     it = placed.emplace(cls * 4 + id, off).first;
+                    wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
+                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, wset)) { delete b; return JD_E_TABLE; }
                     key.append((const char*)h.bits, 16); key.append((const char*)h.vals, h.nvals); key.push_back((char)(cls * 4 + id));
                 }
                 (cls ? im.ac_lut : im.dc_lut)[c] = it->second;
+                (cls ? im.wac : im.wdc)[c] = wplaced[cls * 4 + id];
             }
             key.push_back((char)(0x40 | (f.comp[c].td << 2) | f.comp[c].ta));
             memcpy(im.q[c], f.qt[f.comp[c].tq], 64);
         }
         while (set.size() % 8) { set.push_back(0); sset.push_back(0); }
+        while (wset.size() % 4) wset.push_back(0);
         auto sit = seen.find(key);
         if (sit == seen.end()) {
             sit = seen.emplace(key, std::make_pair((uint32_t)lut.size(), (uint32_t)set.size())).first;
             lut.insert(lut.end(), set.begin(), set.end());
             lut.insert(lut.end(), sset.begin(), sset.end());
+            const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wset.data());
+            lut.insert(lut.end(), w16, w16 + wset.size() * 2);
         }
         im.lut_off = sit->second.first; im.lut_len = sit->second.second;
+        im.w_off = im.lut_off + 2u * im.lut_len; im.w_len = (uint32_t)wset.size();
         b->max_lut_bytes = std::max<uint32_t>(b->max_lut_bytes, im.lut_len * 2u);
+        b->max_w_bytes = std::max<uint32_t>(b->max_w_bytes, im.w_len * 4u);
         // workspace slices
         b->own_ecs_off[i] = ecs_own; ecs_own += align_up(ecs_cap[i] + 16, 256);
         b->own_rgb_off[i] = rgb_own; rgb_own += align_up((size_t)f.width * 3 * f.height, 256);
@@ -356,7 +365,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         im.row_stride = (uint32_t)f.width * 3;
         im.ecs_len = 0;
     }
-    if (b->max_lut_bytes > 160 * 1024 - JD_W_WAVES * JD_WAVE_LDS - 1024) { delete b; return JD_E_TABLE; }
+    if (b->max_w_bytes > 160 * 1024 - JD_W_WAVES * JD_WAVE_LDS - 1024 || b->max_lut_bytes > 44 * 1024 /* sync pass: 64 KiB of LDS less its rings */) { delete b; return JD_E_TABLE; }
     b->rgb_own_bytes = rgb_own; b->stream_bytes = stream; b->coef_elems = coef;
 
     size_t tot = 0;
@@ -531,7 +540,7 @@ extern "C" int jd_batch_wait(jd_batch* b) {
         HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));
         for (const auto& r : b->clear_ranges) HIPCHK(hipMemsetAsync(b->d_coef + r.first, 0, r.second * sizeof(int16_t), s));
         jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[b->n], s);          // restores K0 status bits (idempotent)
-        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[b->n], b->max_lut_bytes, s);
+        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[b->n], b->max_w_bytes, s);
         jdk_launch_sync_spine(a, s);
         int rc = enqueue_stage(b, ST_HUFF_WRITE, s); if (rc) return rc;
         rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;

@@ -15,6 +15,22 @@
 #define JD_LUT_PRIMARY (1 << JD_LUT_BITS)
 #define JD_LUT_SECONDARY 64
 
+// ---- writer tables (32-bit entries) ------------------------------------------------------------------
+// The whole-block writer decodes through its own tables, laid out so that the symbol step needs no left shifts
+// and almost no field extraction (on gfx950 right shifts, and/xor/add issue at twice the rate of left shifts,
+// bit-field extracts and three-operand forms).  One table = 2^JD_W32_BITS primary entries indexed by the next
+// JD_W32_BITS bits of the stream + 128-entry secondary tables indexed by the 7 bits after them.
+//   bit 31 = 0 : [4:0]   32 - (code length + magnitude bits): how far to shift the window right to bring the
+//                        magnitude bits down -- a shift uses only these five bits, so the entry is the operand
+//                [15:8]  byte advance inside the block: 2 * (run + 1); 32 for ZRL; 254 for EOB; 0 for DC
+//                [30:16] magnitude mask 2^size - 1
+//   bit 31 = 1 : [30:0] offset (in entries, from the table start) of the secondary table
+//   0          : no code starts with these bits (invalid)
+#define JD_W32_BITS 9
+#define JD_W32_PRIMARY (1 << JD_W32_BITS)
+#define JD_W32_SECONDARY 128
+#define JD_W32_EOB_ADV 254u
+
 // self-synchronising decode: bits per sub-sequence (one lane each)
 #define JD_SUBSEQ_BITS 4096u
 #define JD_SYNC_WG 256
@@ -25,9 +41,9 @@
 #define JD_SYNC_OWN (JD_SYNC_WG - JD_SYNC_WARM)
 
 // whole-block Huffman writer: waves per workgroup (they share the lookup tables) and LDS bytes per wave
-// (per lane a 64-byte half-block slot + a 64-byte stream ring, plus 256 bytes of dump words)
+// (per lane a 64-byte half-block slot + a 64-byte stream ring, plus one dump word)
 #define JD_W_WAVES 8
-#define JD_WAVE_LDS (64u * 128u + 256u)
+#define JD_WAVE_LDS (64u * 128u + 64u)
 
 // unstuff pass: bytes per workgroup
 #define JD_K0_THREADS 256
@@ -72,6 +88,9 @@ struct JdImg {
                                    // the sync pass's twin set (multi-symbol AC tables, same layout) follows at
                                    // lut_off + lut_len
     uint32_t tile_base, n_tiles; // IDCT/colour tiles
+    uint32_t w_off, w_len;       // writer tables (32-bit entries): u16 offset in the LUT buffer (16-byte aligned) and
+                                 // length in entries (multiple of 4)
+    uint32_t wdc[3], wac[3];     // per component: entry offset of its DC / AC writer table inside that set
     uint32_t pad0;
     uint64_t stream_off;         // byte offset of this image's region in the unstuffed buffer
     uint64_t coef_off;           // int16 offset in the coefficient buffer

@@ -347,19 +347,57 @@ __device__ __forceinline__ uint32_t lut_lookup(uint32_t tb, uint32_t win, uint32
     return e;
 }
 
+// The writer addresses LDS by absolute byte address (the base of dyn_lds is folded into its per-lane bases once),
+// so that no access pays an add of the array's link-time address.
+typedef __attribute__((address_space(3))) uint8_t* jd_lds_ptr;
+__device__ __forceinline__ uint32_t lds_abs_base() { return (uint32_t)(uintptr_t)(jd_lds_ptr)dyn_lds; }
+__device__ __forceinline__ uint32_t la_u32(uint32_t addr) { return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)addr; }
+typedef uint32_t jd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 la_u4(uint32_t addr) {
+    const jd_u32x4 v = *(__attribute__((address_space(3))) const jd_u32x4*)(uintptr_t)addr;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void la_st16(uint32_t addr, int v) { *(__attribute__((address_space(3))) int16_t*)(uintptr_t)addr = (int16_t)v; }
+__device__ __forceinline__ void la_st4(uint32_t addr, uint4 v) {
+    jd_u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *(__attribute__((address_space(3))) jd_u32x4*)(uintptr_t)addr = t;
+}
+
+// writer tables (32-bit entries, jd_internal.h): an invalid code reads as "one bit, end of block"
+#define JD_W32_SKIP (31u | (JD_W32_EOB_ADV << 8))
+__device__ __forceinline__ uint32_t w32_lookup(uint32_t tb, uint32_t win, uint32_t& bad) {
+    uint32_t e = la_u32(tb + ((win >> (30 - JD_W32_BITS)) & ((JD_W32_PRIMARY - 1u) << 2)));
+    if (__builtin_expect((int)e <= 0, 0)) {                        // secondary table, or no such code
+        const uint32_t o = e & 0x7FFFFFFFu;
+        e = o ? la_u32(tb + (o << 2) + ((win >> (30 - JD_W32_BITS - 7)) & (127u << 2))) : 0u;
+        if ((int)e <= 0) { bad = 1; e = JD_W32_SKIP; }
+    }
+    return e;
+}
+// magnitude bits + EXTEND (main.go:196-198 / 234-236) from a writer-table entry: v < 2^(size-1) -> v - (2^size - 1)
+__device__ __forceinline__ int w32_value(uint32_t win, uint32_t e) {
+    const uint32_t m = e >> 16;
+    const uint32_t raw = (win >> (e & 31u)) & m;
+    return (int)raw - (int)(raw <= (e >> 17) ? m : 0u);            // e >> 17 = 2^(size-1) - 1
+}
+
 __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
                                                const Segment& sg, uint32_t slen, uint32_t err) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t wbase = lut_bytes + wv * JD_WAVE_LDS;                 // lut_bytes: multiple of 128
+    const uint32_t lbase = lds_abs_base();                               // multiple of 128 (dyn_lds is the kernel's only LDS)
+    const uint32_t wbase = lbase + lut_bytes + wv * JD_WAVE_LDS;         // lut_bytes: multiple of 128
     const uint32_t slot_b = wbase + lane * 64u;                          // byte offsets inside dyn_lds
     const uint32_t ring_b = wbase + 4096u + lane * 64u;
-    const uint32_t dump_b = wbase + 8192u + lane * 4u;                   // where coefficient-less symbols "store"
+    uint32_t dump_b = wbase + 8192u;                                     // where out-of-phase symbols "store"
+    uint32_t four = 4u;
+    asm volatile("" : "+v"(dump_b), "+v"(four));                         // in VGPRs: selects against them stay two-operand
     const uint32_t rot = (lane & 3u) << 4;                               // slot swizzle and ring rotation (4 chunks each)
 #pragma unroll
-    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(dyn_lds + slot_b + i * 16) = make_uint4(0, 0, 0, 0);
-    const ImgK ik = load_imgk(im);
-    const uint32_t bpm = ik.bpm;
+    for (int i = 0; i < 4; i++) la_st4(slot_b + i * 16, make_uint4(0, 0, 0, 0));
+    const uint32_t bpm = im.bpm, nl = im.hs * im.vs;
+    const uint32_t dc0 = lbase + im.wdc[0] * 4u, dc1 = lbase + im.wdc[1] * 4u, dc2 = lbase + im.wdc[2] * 4u;   // table addresses
+    const uint32_t ac0 = lbase + im.wac[0] * 4u, ac1 = lbase + im.wac[1] * 4u, ac2 = lbase + im.wac[2] * 4u;
 
     // ---- prime the ring: four quads, synchronously -----------------------------------------------------
     const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
@@ -370,7 +408,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
         const uint4 v = Q[qbase + k < qmax ? qbase + k : qmax];
-        *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((k * 16u + rot) & 63u))) = be32x4(v);
+        la_st4(ring_b | ((k * 16u + rot) & 63u), be32x4(v));
     }
     // Ring bookkeeping in byte units with the lane's rotation folded in:
     //   rpb = 4 * (dwords taken from the ring) + rot      wqb = 16 * (quads written to the ring) + rot
@@ -378,10 +416,10 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     uint32_t wqb = 64u + rot;
     uint32_t rpb = (g & 3u) * 4u + rot;
     wave_lds_order();
-    auto ring_at = [&](uint32_t xb) { return lds_u32(ring_b | (xb & 63u)); };
+    auto ring_at = [&](uint32_t xb) { return la_u32(ring_b | (xb & 63u)); };
     uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 4), nxt = ring_at(rpb + 8);
     rpb += 12;
-    int sh = 32 - (int)o0;                                               // window = alignbit(w0, w1, sh), sh in [0,31]
+    uint32_t sh = 32u - o0;                                              // window = alignbit(w0, w1, sh), sh in [0,31]
     uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;                       // quads requested, not yet in the ring
     uint32_t npend = 0;
 
@@ -416,8 +454,8 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     // Requested quads are committed just before the block stores of the same half step are issued: vmcnt counts in
     // order, so a wait placed after those stores would also wait for them to reach memory.
     auto commit = [&]() {
-        if (npend >= 1) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 63u))) = be32x4(pq0);
-        if (npend >= 2) *reinterpret_cast<uint4*>(dyn_lds + (ring_b | ((wqb + 16u) & 63u))) = be32x4(pq1);
+        if (npend >= 1) la_st4(ring_b | (wqb & 63u), be32x4(pq0));
+        if (npend >= 2) la_st4(ring_b | ((wqb + 16u) & 63u), be32x4(pq1));
         wqb += npend * 16u; npend = 0;
     };
     // The ring word that the next refill needs is read at the top of every symbol step, beside the table
@@ -428,90 +466,91 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
             commit();
             if (rpb >= wqb) {
                 const uint4 v = Q[quad_index(wqb)];
-                *reinterpret_cast<uint4*>(dyn_lds + (ring_b | (wqb & 63u))) = be32x4(v);
+                la_st4(ring_b | (wqb & 63u), be32x4(v));
                 wqb += 16u;
             }
         }
         wave_lds_order();
     };
-    // consume `total` bits; branch-free refill from `cand`
-    auto advance = [&](uint32_t total, uint32_t cand) {
-        sh -= (int)total;
-        const bool r = sh < 0;
+    // consume the entry's bits (e[4:0] = 32 - bits): sh + that is < 32 exactly when the window has moved past w0
+    auto advance = [&](uint32_t e, uint32_t cand) {
+        const uint32_t t = sh + (e & 31u);
+        const bool r = t < 32u;
+        sh = t & 31u;
         w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
-        sh += r ? 32 : 0; rpb += r ? 4u : 0u;
+        rpb += r ? four : 0u;
     };
     auto flush = [&](uint32_t b, uint32_t half) {                        // 4 lanes move one 64-byte half block
 #pragma unroll
         for (uint32_t r = 0; r < 4; r++) {
-            uint4* src = reinterpret_cast<uint4*>(dyn_lds + f_src + r * 1024u);
-            const uint4 v = *src;
-            *src = make_uint4(0, 0, 0, 0);
+            const uint4 v = la_u4(f_src + r * 1024u);
+            la_st4(f_src + r * 1024u, make_uint4(0, 0, 0, 0));
             if (b < f_nblk[r]) *reinterpret_cast<uint4*>(f_dst[r] + (uint64_t)b * 64u + half * 32u) = v;
         }
     };
 
+    // `o` = byte offset, inside the current half block, of the coefficient the last symbol produced.  A symbol adds
+    // its advance (2 * (run + 1); 254 for EOB, far outside either half) and stores its value at the new offset when
+    // that lies in the half being assembled (else to the dump word); ZRL stores a zero on a zero.
+    const uint32_t idle = 1u << 20;
 #pragma unroll 1
     for (uint32_t b = 0; b < nmax; b++) {
         request(b < sg.nblk);
         wave_lds_order();
         // ---- tables of this block's component -----------------------------------------------------------
-        const uint32_t comp = c < ik.nl ? 0u : c - ik.nl + 1u;
-        const uint32_t dcb = sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u;      // byte offsets into the LUT
-        const uint32_t acb = sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
-        uint32_t z = 64, zlast = 63, size = 0;
+        const uint32_t comp = c < nl ? 0u : c - nl + 1u;
+        const uint32_t dcb = sel3(comp, dc0, dc1, dc2);
+        const uint32_t acb = sel3(comp, ac0, ac1, ac2);
+        uint32_t o = idle, e = 0;
         int v = 0;
         if (b < sg.nblk) {
             // DC: category, magnitude bits, EXTEND, prediction (main.go:188-201)
             if (__builtin_amdgcn_ballot_w64(rpb >= wqb)) top_up_now();
             const uint32_t cand = ring_at(rpb);
-            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
-            const uint32_t e = lut_lookup(dcb, win, bad);
-            const uint32_t total = e & 31u;
-            const int diff = extend_bits(win, total, (e >> 5) & 15u);
-            advance(total, cand);
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
+            e = w32_lookup(dcb, win, bad);
+            const int diff = w32_value(win, e);
+            advance(e, cand);
             const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
             p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
-            *reinterpret_cast<int16_t*>(dyn_lds + slot_b + rot) = (int16_t)pred;   // coefficient 0: chunk 0 ^ (lane & 3)
-            z = 1;
+            la_st16(slot_b + rot, pred);   // coefficient 0: chunk 0 ^ (lane & 3)
+            o = 0;
         }
         // ---- AC, first half: symbols until every lane has passed coefficient 31 (main.go:204-239) ----------
-        while (z < 32u) {                                         // divergent loop: finished lanes drop out
+        while (o < 62u) {                                         // divergent loop: finished lanes drop out
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
             const uint32_t cand = ring_at(rpb);
-            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
-            const uint32_t e = lut_lookup(acb, win, bad);
-            const uint32_t total = e & 31u;
-            size = (e >> 5) & 15u; zlast = (e >> 9) & 63u;
-            v = extend_bits(win, total, size);
-            advance(total, cand);
-            z += zlast + 1u;
-            // a symbol without a coefficient (EOB, ZRL) or one that lands in the other half stores to a dump word
-            const uint32_t at = (size != 0 && z <= 32u) ? slot_b + ((z * 2u - 2u) ^ rot) : dump_b;
-            *reinterpret_cast<int16_t*>(dyn_lds + at) = (int16_t)v;
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
+            e = w32_lookup(acb, win, bad);
+            v = w32_value(win, e);
+            advance(e, cand);
+            o += (e >> 8) & 255u;
+            const uint32_t at = o < 64u ? slot_b + (o ^ rot) : dump_b;
+            la_st16(at, v);
         }
         commit();
         wave_lds_order();
         flush(b, 0);
         wave_lds_order();
-        request(b < sg.nblk && z < 64u);
+        o -= 64u;                                                 // offsets of the second half (wraps below zero for 62)
+        request((int)o < 62);
         // the symbol that crossed into the second half left its coefficient for now
-        if (b < sg.nblk && size != 0 && z > 32u && z <= 64u) *reinterpret_cast<int16_t*>(dyn_lds + slot_b + ((z * 2u - 66u) ^ rot)) = (int16_t)v;
+        if (o < 64u) la_st16(slot_b + (o ^ rot), v);
         // ---- AC, second half ----------------------------------------------------------------------------------
-        while (z < 64u) {
+        while ((int)o < 62) {
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
             const uint32_t cand = ring_at(rpb);
-            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
-            const uint32_t e = lut_lookup(acb, win, bad);
-            const uint32_t total = e & 31u;
-            size = (e >> 5) & 15u; zlast = (e >> 9) & 63u;
-            v = extend_bits(win, total, size);
-            advance(total, cand);
-            z += zlast + 1u;
-            const uint32_t at = (size != 0 && z <= 64u) ? slot_b + ((z * 2u - 66u) ^ rot) : dump_b;
-            *reinterpret_cast<int16_t*>(dyn_lds + at) = (int16_t)v;
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
+            e = w32_lookup(acb, win, bad);
+            v = w32_value(win, e);
+            advance(e, cand);
+            o += (e >> 8) & 255u;
+            const uint32_t at = o < 64u ? slot_b + (o ^ rot) : dump_b;
+            la_st16(at, v);
         }
-        if (b < sg.nblk && z > 64u && zlast != 63u) err |= JD_ST_COEF;      // run walked past coefficient 63
+        // a block ends at offset 62 exactly (coefficient 63) or by EOB (>= 254 - 64 - 2); in between = a run that
+        // walked past coefficient 63
+        if ((int)o > 62 && o < 124u) err |= JD_ST_COEF;
         commit();
         wave_lds_order();
         flush(b, 1);
@@ -523,7 +562,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
         // bit position = 32 * (dwords consumed before w0) + bits of w0 consumed; w0 is ring dword (rp - 3) and
         // the front pad holds 4 dwords
         const uint32_t rp = (rpb - rot) >> 2;
-        const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - (uint32_t)sh);
+        const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - sh);
         if (pos > sg.end_bit) err |= JD_ST_TRUNC;                 // ran past the segment: data ended early
     }
     if (err) atomicOr(&a.status[img], err);
@@ -533,7 +572,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
-    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.lut_off, im.lut_len);
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
     const uint32_t ri = im.restart_interval;
     const uint32_t iv = (blockIdx.x - a.prefix[img]) * (64u * JD_W_WAVES) + threadIdx.x;
     const uint32_t slen = a.stream_len[img];
@@ -796,7 +835,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs 
     const uint32_t L = lw * (64u * JD_W_WAVES) + threadIdx.x;
     const uint32_t swg = L / JD_SYNC_WG, sl = L % JD_SYNC_WG;
     if ((lw * (64u * JD_W_WAVES) / JD_SYNC_WG) * JD_SYNC_OWN >= nsub) return;   // whole workgroup past the stream
-    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.lut_off, im.lut_len);
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
     const uint32_t s = swg * JD_SYNC_OWN + sl;
     const bool active = sl < JD_SYNC_OWN && s < nsub && swg < im.n_sync_wg;
     Segment sg; sg.start_bit = 0; sg.end_bit = sbits; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
