@@ -314,7 +314,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         std::string key;
         std::vector<uint16_t> set, sset;                          // single-symbol tables / sync-pass twin (same layout)
         std::vector<uint32_t> wset;                               // writer tables (32-bit entries)
-        std::map<int, uint32_t> placed, wplaced;                  // class*4+id -> entry offset in set / wset
+        std::map<int, uint32_t> placed, wplaced, splaced;         // class*4+id -> entry offset in set / wset / sset
         for (int c = 0; c < f.ncomp; c++) {
             for (int cls = 0; cls < 2; cls++) {
                 const int id = cls ? f.comp[c].ta : f.comp[c].td;
@@ -323,8 +323,9 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
                 if (it == placed.end()) {
                     const uint32_t off = (uint32_t)set.size();
                     if (jd_pack_lut(h.bits, h.vals, h.nvals, cls == 0, set)) { delete b; return JD_E_TABLE; }
-                    if (cls == 0) jd_pack_lut(h.bits, h.vals, h.nvals, true, sset);
-                    else jd_pack_lut_multi(h.bits, h.vals, h.nvals, sset);
+                    splaced.emplace(cls * 4 + id, (uint32_t)sset.size());
+                    if (cls == 0) jd_pack_lut_bits(h.bits, h.vals, h.nvals, true, JD_SLUT_BITS, sset);
+                    else jd_pack_lut_multi(h.bits, h.vals, h.nvals, JD_SLUT_BITS, sset);
                     it = placed.emplace(cls * 4 + id, off).first;
                     wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
                     if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, wset)) { delete b; return JD_E_TABLE; }
@@ -332,11 +333,13 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
                 }
                 (cls ? im.ac_lut : im.dc_lut)[c] = it->second;
                 (cls ? im.wac : im.wdc)[c] = wplaced[cls * 4 + id];
+                (cls ? im.sac : im.sdc)[c] = splaced[cls * 4 + id];
             }
             key.push_back((char)(0x40 | (f.comp[c].td << 2) | f.comp[c].ta));
             memcpy(im.q[c], f.qt[f.comp[c].tq], 64);
         }
-        while (set.size() % 8) { set.push_back(0); sset.push_back(0); }
+        while (set.size() % 8) set.push_back(0);
+        while (sset.size() % 8) sset.push_back(0);
         while (wset.size() % 4) wset.push_back(0);
         auto sit = seen.find(key);
         if (sit == seen.end()) {
@@ -347,8 +350,9 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
             lut.insert(lut.end(), w16, w16 + wset.size() * 2);
         }
         im.lut_off = sit->second.first; im.lut_len = sit->second.second;
-        im.w_off = im.lut_off + 2u * im.lut_len; im.w_len = (uint32_t)wset.size();
-        b->max_lut_bytes = std::max<uint32_t>(b->max_lut_bytes, im.lut_len * 2u);
+        im.s_len = (uint32_t)sset.size();
+        im.w_off = im.lut_off + im.lut_len + im.s_len; im.w_len = (uint32_t)wset.size();
+        b->max_lut_bytes = std::max<uint32_t>(b->max_lut_bytes, im.s_len * 2u);
         b->max_w_bytes = std::max<uint32_t>(b->max_w_bytes, im.w_len * 4u);
         // workspace slices
         b->own_ecs_off[i] = ecs_own; ecs_own += align_up(ecs_cap[i] + 16, 256);

@@ -14,6 +14,10 @@
 #define JD_LUT_BITS 10
 #define JD_LUT_PRIMARY (1 << JD_LUT_BITS)
 #define JD_LUT_SECONDARY 64
+// primary index bits of the sync pass's twin tables (multi-symbol AC entries: a wider window holds more symbols)
+#ifndef JD_SLUT_BITS
+#define JD_SLUT_BITS 10
+#endif
 
 // ---- writer tables (32-bit entries) ------------------------------------------------------------------
 // The whole-block writer decodes through its own tables, laid out so that the symbol step needs no left shifts
@@ -88,6 +92,8 @@ struct JdImg {
                                    // the sync pass's twin set (multi-symbol AC tables, same layout) follows at
                                    // lut_off + lut_len
     uint32_t tile_base, n_tiles; // IDCT/colour tiles
+    uint32_t s_len;              // u16 length of the sync twin set (at lut_off + lut_len)
+    uint32_t sdc[3], sac[3];     // per component: entry offset of its DC / AC table inside the twin set
     uint32_t w_off, w_len;       // writer tables (32-bit entries): u16 offset in the LUT buffer (16-byte aligned) and
                                  // length in entries (multiple of 4)
     uint32_t wdc[3], wac[3];     // per component: entry offset of its DC / AC writer table inside that set

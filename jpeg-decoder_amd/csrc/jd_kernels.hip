@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelAr
 // LDS map of k1_sync (byte offsets in dyn_lds)
 #define JD_SY_RINGS 0u
 #define JD_SY_DCSUM ((JD_SYNC_WG / 64u) * JD_SPEC_RING_BYTES)  // [3 components][JD_SYNC_WG lanes] ints
-#define JD_SY_CTAB (JD_SY_DCSUM + 3u * JD_SYNC_WG * 4u)         // per block-in-MCU: dcb | acb << 15 | comp << 30
+#define JD_SY_CTAB (JD_SY_DCSUM + 3u * JD_SYNC_WG * 4u)         // per block-in-MCU: dcb/4 | acb/4 << 15 | comp << 30
 #define JD_SY_LUT (JD_SY_CTAB + 64u)
 
 __device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<int*>(__builtin_assume_aligned(dyn_lds + off, 4)); }
@@ -669,7 +669,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     uint32_t c = (entry >> 8) & 0xFFu, z = (entry >> 16) & 0x7Fu;
     if (c >= ik.bpm) c = 0;
     uint32_t t = lds_u32(JD_SY_CTAB + c * 4u);
-    uint32_t dcb = t & 0x7FFFu, acb = (t >> 15) & 0x7FFFu, csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
+    uint32_t dcb = (t & 0x7FFFu) << 2, acb = ((t >> 15) & 0x7FFFu) << 2, csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
     uint32_t nstart = 0, first = 0;
     *lds_int(dcs_l) = 0; *lds_int(dcs_l + JD_SYNC_WG * 4u) = 0; *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u) = 0;
     wave_lds_order();
@@ -678,10 +678,10 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
         const uint32_t cand = ring_at(rpb);
         const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
         const uint32_t tb = z ? acb : dcb;
-        uint32_t e = lds_u16(tb + ((win >> (32 - JD_LUT_BITS)) << 1));
+        uint32_t e = lds_u16(tb + ((win >> (32 - JD_SLUT_BITS)) << 1));
         if (__builtin_expect((e & 0x8000u) != 0 || e == 0, 0)) {
             const uint32_t o = e & 0x7FFFu;
-            e = (e && o) ? lds_u16(tb + (o << 1) + (((win >> (32 - JD_LUT_BITS - 6)) & 63u) << 1)) : 0u;
+            e = (e && o) ? lds_u16(tb + (o << 1) + (((win >> (32 - JD_SLUT_BITS - 6)) & 63u) << 1)) : 0u;
             if (e == 0) e = 1;                                            // speculative: step over one bit
         }
         uint32_t total = e & 31u;
@@ -699,7 +699,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
             // next block -- redo the step with one symbol from the writer's table
             const bool ok = zn == 64u || (zn - z >= 64u && zn < 128u);
             if (!ok) {
-                const uint16_t* gt = lutg + ((acb - JD_SY_LUT) >> 1);
+                const uint16_t* gt = lutg + sel3(t >> 30, ik.ac0, ik.ac1, ik.ac2);   // single-symbol table (global memory)
                 uint32_t e1 = gt[win >> (32 - JD_LUT_BITS)];
                 if (e1 & 0x8000u) e1 = (e1 & 0x7FFFu) ? gt[(e1 & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)] : 0u;
                 if (e1 == 0) e1 = 1;
@@ -716,7 +716,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
             z = 0;
             c = (c + 1u == ik.bpm) ? 0u : c + 1u;
             t = lds_u32(JD_SY_CTAB + c * 4u);
-            dcb = t & 0x7FFFu; acb = (t >> 15) & 0x7FFFu; csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
+            dcb = (t & 0x7FFFu) << 2; acb = ((t >> 15) & 0x7FFFu) << 2; csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
         }
     }
     wave_lds_order();
@@ -745,10 +745,10 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     if (threadIdx.x < 16u) {
         const uint32_t cc = threadIdx.x < ik.bpm ? threadIdx.x : 0u;
         const uint32_t comp = cc < ik.nl ? 0u : cc - ik.nl + 1u;
-        const uint32_t d = JD_SY_LUT + sel3(comp, ik.dc0, ik.dc1, ik.dc2) * 2u, ac = JD_SY_LUT + sel3(comp, ik.ac0, ik.ac1, ik.ac2) * 2u;
-        *reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_CTAB + threadIdx.x * 4u) = d | (ac << 15) | (comp << 30);
+        const uint32_t d = JD_SY_LUT + sel3(comp, im.sdc[0], im.sdc[1], im.sdc[2]) * 2u, ac = JD_SY_LUT + sel3(comp, im.sac[0], im.sac[1], im.sac[2]) * 2u;
+        *reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_CTAB + threadIdx.x * 4u) = (d >> 2) | ((ac >> 2) << 15) | (comp << 30);
     }
-    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + JD_SY_LUT), a.lut + im.lut_off + im.lut_len, im.lut_len);   // sync twin set
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + JD_SY_LUT), a.lut + im.lut_off + im.lut_len, im.s_len);   // sync twin set
     const int si = (int)(lw * JD_SYNC_OWN + threadIdx.x) - JD_SYNC_WARM;
     const uint32_t s = si < 0 ? 0u : (uint32_t)si;
     const bool owned = threadIdx.x >= JD_SYNC_WARM && s < nsub;

@@ -24,22 +24,27 @@ static inline uint16_t make_entry(bool is_dc, unsigned sym, unsigned len) {
 }
 
 int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, std::vector<uint16_t>& out) {
+    return jd_pack_lut_bits(bits, vals, nvals, is_dc, JD_LUT_BITS, out);
+}
+
+int jd_pack_lut_bits(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned lut_bits, std::vector<uint16_t>& out) {
+    const unsigned primary = 1u << lut_bits;
     int count = 0;
     for (int i = 0; i < 16; i++) count += bits[i];
     if (count != nvals || nvals > 256) return -1;
     const size_t base = out.size();
-    out.resize(base + JD_LUT_PRIMARY, 0);
+    out.resize(base + primary, 0);
     unsigned code = 0;
     int k = 0;
     for (unsigned len = 1; len <= 16; len++) {
         for (int i = 0; i < bits[len - 1]; i++, k++) {
             if (code >= (1u << len)) return -2;                       // over-subscribed code space
             const uint16_t e = make_entry(is_dc, vals[k], len);
-            if (len <= JD_LUT_BITS) {
-                const unsigned first = code << (JD_LUT_BITS - len), n = 1u << (JD_LUT_BITS - len);
+            if (len <= lut_bits) {
+                const unsigned first = code << (lut_bits - len), n = 1u << (lut_bits - len);
                 for (unsigned j = 0; j < n; j++) out[base + first + j] = e;
             } else {
-                const unsigned prefix = code >> (len - JD_LUT_BITS);
+                const unsigned prefix = code >> (len - lut_bits);
                 uint16_t p = out[base + prefix];
                 if (!(p & 0x8000u)) {
                     if (p != 0) return -2;                            // prefix already a complete code
@@ -49,7 +54,8 @@ int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_
                     p = (uint16_t)(0x8000u | off);
                     out[base + prefix] = p;
                 }
-                const unsigned sub = (code << (16 - len)) & 63u, n = 1u << (16 - len);
+                // secondary tables are indexed by the 6 bits after the primary ones
+                const unsigned sub = (code << (lut_bits + 6 - len)) & 63u, n = 1u << (lut_bits + 6 - len);
                 for (unsigned j = 0; j < n; j++) out[base + (p & 0x7FFFu) + sub + j] = e;
             }
             code++;
@@ -69,9 +75,10 @@ int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_
 // otherwise it falls back to one symbol from the writer's table.
 static inline uint16_t sync_entry(unsigned total, unsigned a, unsigned eob) { return (uint16_t)(total | ((a + 64u * eob) << 5)); }
 
-int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint16_t>& out) {
+int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, unsigned lut_bits, std::vector<uint16_t>& out) {
+    const unsigned primary = 1u << lut_bits;
     const size_t base = out.size();
-    const int rc = jd_pack_lut(bits, vals, nvals, false, out);
+    const int rc = jd_pack_lut_bits(bits, vals, nvals, false, lut_bits, out);
     if (rc) return rc;
     const std::vector<uint16_t> single(out.begin() + base, out.end());
     for (size_t i = 0; i < single.size(); i++) {                  // every complete-symbol entry: new format
@@ -80,13 +87,13 @@ int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, st
         const unsigned zinc = ((e >> 9) & 63u) + 1u;
         out[base + i] = zinc == 64 ? sync_entry(e & 31u, 0, 1) : sync_entry(e & 31u, zinc, 0);
     }
-    for (unsigned w = 0; w < JD_LUT_PRIMARY; w++) {               // primary entries: greedy groups
+    for (unsigned w = 0; w < primary; w++) {                      // primary entries: greedy groups
         unsigned pos = 0, a = 0, eob = 0, nsym = 0;
-        while (pos < JD_LUT_BITS && !eob) {
-            const uint16_t e = single[(w << pos) & (JD_LUT_PRIMARY - 1)];
+        while (pos < lut_bits && !eob) {
+            const uint16_t e = single[(w << pos) & (primary - 1)];
             if (e == 0 || (e & 0x8000u)) break;
             const unsigned total = e & 31u, zinc = ((e >> 9) & 63u) + 1u;
-            if (pos + total > JD_LUT_BITS) break;                 // not wholly inside the known bits
+            if (pos + total > lut_bits) break;                    // not wholly inside the known bits
             if (zinc == 64) eob = 1;
             else if (a + zinc > 63) break;
             else a += zinc;

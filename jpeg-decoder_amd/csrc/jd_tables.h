@@ -10,6 +10,8 @@
 // Returns 0, -1 (counts do not match), -2 (not a prefix code), -3 (too large).
 int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, std::vector<uint16_t>& out);
 // AC table for the self-synchronising pass: several whole symbols per primary entry (see jd_tables.cpp).
-int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint16_t>& out);
+int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, unsigned lut_bits, std::vector<uint16_t>& out);
+// jd_pack_lut with a primary table of 2^lut_bits entries (the sync pass's tables are wider than the fallback ones)
+int jd_pack_lut_bits(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned lut_bits, std::vector<uint16_t>& out);
 // Writer table (32-bit entries, JD_W32_BITS-bit primary + 128-entry secondaries; layout in jd_internal.h).
 int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, std::vector<uint32_t>& out);
