@@ -1224,17 +1224,23 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 if (JD_K2_ABL & 2) { d[0] = smp[i * 4] ^ cq[0][r * 2]; d[1] = smp[i * 4 + 1] ^ cq[1][r * 2]; d[2] = smp[i * 4 + 2] ^ cq[0][r * 2 + 1]; d[3] = smp[i * 4 + 3] ^ cq[1][r * 2 + 1]; }
                 else
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t yw = smp[i * 4 + (j >> 1)];
-                    const int yi = (j & 1) ? ((int)yw >> 16) : (int)(short)(yw & 0xFFFFu);
-                    const float y = (float)yi;
-                    const int k = j >> 1;
-                    const float R = __fadd_rn(__fadd_rn(y, rc[k]), 128.0f);
-                    const float G = __fadd_rn(__fsub_rn(__fsub_rn(y, gb[k]), gr[k]), 128.0f);
-                    const float B = __fadd_rn(__fadd_rn(y, bc[k]), 128.0f);
-                    d[(3 * j) >> 2] = put_u8(R, (3 * j) & 3, d[(3 * j) >> 2]);
-                    d[(3 * j + 1) >> 2] = put_u8(G, (3 * j + 1) & 3, d[(3 * j + 1) >> 2]);
-                    d[(3 * j + 2) >> 2] = put_u8(B, (3 * j + 2) & 3, d[(3 * j + 2) >> 2]);
+                for (int k = 0; k < 4; k++) {
+                    // the two pixels that share chroma sample k, as one packed-f32 pair: the same additions in the same
+                    // order as main.go:679-703, two at a time
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const uint32_t yw = smp[i * 4 + k];
+                    const f32x2 y = { (float)(int)(short)(yw & 0xFFFFu), (float)((int)yw >> 16) };
+                    const f32x2 off = { 128.0f, 128.0f };
+                    const f32x2 R = (y + f32x2{ rc[k], rc[k] }) + off;
+                    const f32x2 G = ((y - f32x2{ gb[k], gb[k] }) - f32x2{ gr[k], gr[k] }) + off;
+                    const f32x2 B = (y + f32x2{ bc[k], bc[k] }) + off;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int j = 2 * k + u;
+                        d[(3 * j) >> 2] = put_u8(R[u], (3 * j) & 3, d[(3 * j) >> 2]);
+                        d[(3 * j + 1) >> 2] = put_u8(G[u], (3 * j + 1) & 3, d[(3 * j + 1) >> 2]);
+                        d[(3 * j + 2) >> 2] = put_u8(B[u], (3 * j + 2) & 3, d[(3 * j + 2) >> 2]);
+                    }
                 }
                 if (Yp < H && pair) {
                     uint8_t* stage = dyn_lds + 8192u + (uint32_t)i * 1536u + lane * 24u;
