@@ -432,17 +432,29 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nmax, d, 64); nmax = t > nmax ? t : nmax; }
 
-    // flush plan (one half block = 64 bytes): in pass r lanes 4t'..4t'+3 move the half of lane t = 16r + (lane >> 2)
-    const uint32_t part = lane & 3u;
-    uint32_t f_nblk[4];
-    int16_t* f_dst[4];
+    // flush plan: a block leaves as ONE 128-byte line written by 8 lanes (16 B each) of one store instruction -- a
+    // 64-byte store into a line that is not in L2 makes L2 fetch the line, and half-block stores a phase apart cost the
+    // restart-interval writer a quarter of its time.  In pass q lanes 8t'..8t'+7 move the block of lane
+    // t = 8q + (lane >> 3): lanes with bit 2 clear pick up their piece of the first half when that half is complete
+    // and hold it in registers; lanes with bit 2 set pick up the second half; then all eight store.
+    const uint32_t part = lane & 3u, f_hi = (lane >> 2) & 1u;
+    uint32_t blk_first = sg.nblk ? sg.blk0 : 0xFFFFFFFFu;                // the wave's first block: store offsets fit 32 bits
 #pragma unroll
-    for (uint32_t r = 0; r < 4; r++) {
-        const uint32_t t = r * 16u + (lane >> 2);
-        f_nblk[r] = __shfl(sg.nblk, t, 64);
-        f_dst[r] = gbase + (uint64_t)__shfl(sg.blk0, t, 64) * 64u + part * 8u;
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(blk_first, d, 64); blk_first = t < blk_first ? t : blk_first; }
+    blk_first = __builtin_amdgcn_readfirstlane(blk_first == 0xFFFFFFFFu ? 0u : blk_first);
+    uint8_t* const wave_dst = reinterpret_cast<uint8_t*>(gbase + (uint64_t)blk_first * 64u);
+    uint32_t f_nblk[8], f_off[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+        const uint32_t t = q * 8u + (lane >> 3);
+        f_nblk[q] = __shfl(sg.nblk, t, 64);
+        const uint32_t tb0 = __shfl(sg.blk0, t, 64);                     // (unconditional: a shuffle reads active lanes only)
+        f_off[q] = f_nblk[q] ? (tb0 - blk_first) * 128u + (lane & 7u) * 16u : 0u;
     }
-    const uint32_t f_src = wbase + (lane >> 2) * 64u + ((part ^ ((lane >> 2) & 3u)) << 4);   // + r * 1024
+    const uint32_t f_src = wbase + (lane >> 3) * 64u + ((part ^ ((lane >> 3) & 3u)) << 4);   // + q * 512
+    uint4 f_hold[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) f_hold[q] = make_uint4(0, 0, 0, 0);
 
     auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rot) >> 4); return q < qmax ? q : qmax; };
     auto request = [&](bool want) {                                      // up to two quads into the free part of the ring
@@ -481,17 +493,24 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
         w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
         rpb += r ? four : 0u;
     };
-    auto flush = [&](uint32_t b, uint32_t half) {                        // 4 lanes move one 64-byte half block
+    auto flush = [&](uint32_t b, uint32_t half) {
+        if (f_hi == half) {                                              // this lane's half is complete: take it, clear the slot
 #pragma unroll
-        for (uint32_t r = 0; r < 4; r++) {
-            const uint4 v = la_u4(f_src + r * 1024u);
-            la_st4(f_src + r * 1024u, make_uint4(0, 0, 0, 0));
-            if (b < f_nblk[r]) {
-                jd_u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-                jd_u32x4* at = reinterpret_cast<jd_u32x4*>(f_dst[r] + (uint64_t)b * 64u + half * 32u);
-                // measured: streaming (non-temporal) stores take a quarter off the sub-sequence writer's time and add
-                // 8 % to the restart-interval writer's
-                if (NT) __builtin_nontemporal_store(t, at); else *at = t;
+            for (uint32_t q = 0; q < 8; q++) {
+                f_hold[q] = la_u4(f_src + q * 512u);
+                la_st4(f_src + q * 512u, make_uint4(0, 0, 0, 0));
+            }
+        }
+        if (half == 1u) {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                if (b < f_nblk[q]) {
+                    jd_u32x4 t; t.x = f_hold[q].x; t.y = f_hold[q].y; t.z = f_hold[q].z; t.w = f_hold[q].w;
+                    jd_u32x4* at = reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)b * 128u);
+                    // measured: streaming (non-temporal) stores take a quarter off the sub-sequence writer's time and add
+                    // 8 % to the restart-interval writer's
+                    if (NT) __builtin_nontemporal_store(t, at); else *at = t;
+                }
             }
         }
     };
