@@ -166,12 +166,23 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
     uint32_t tot;
     const uint32_t ex = block_excl_scan(nk | (nr << 16), tmp, tot);   // nk <= 64 * 256 < 2^16 per workgroup
     const uint32_t ek = ex & 0xFFFFu, er = ex >> 16, tk = tot & 0xFFFFu, tr = tot >> 16;
-    // ---- publish, look back, publish ------------------------------------------------------------------------
+    // ---- publish this chunk's totals, compact, then look back ------------------------------------------------
+    // The compaction does not need the chunk's place in the output (the copy-out below shifts by the output's 16-byte
+    // phase), so it runs between publishing the totals and reading the predecessors': by the time a workgroup looks
+    // back, the chunks before it have had the same few microseconds to publish, and the look-back rarely waits.
     unsigned long long* st = a.k0_state + gchunk;
+    const unsigned long long mine = (unsigned long long)tk | ((unsigned long long)tr << 28);
+    if (threadIdx.x == 0) __hip_atomic_store(st, mine | (chunk ? JD_K0_AGG : JD_K0_PFX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        uint32_t o = ek;
+#pragma unroll
+        for (int r = 0; r < JD_K0_QUADS; r++)
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (keep[r][j >> 2] & (0x80u << ((j & 3) * 8))) buf[o++] = (uint8_t)(w[r][j >> 2] >> ((j & 3) * 8));
+    }
     if (threadIdx.x < 64) {                                      // wave 0
         const uint32_t lane = threadIdx.x;
-        const unsigned long long mine = (unsigned long long)tk | ((unsigned long long)tr << 28);
-        if (lane == 0) __hip_atomic_store(st, mine | (chunk ? JD_K0_AGG : JD_K0_PFX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long run = 0;                              // sum of the chunks before this one
         int back = (int)chunk - 1;                               // nearest chunk not yet summed
         while (back >= 0) {
@@ -204,14 +215,8 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
     }
     __syncthreads();
     const uint2 base = s_base;                                   // kept bytes / markers before this chunk
-    // ---- compact into LDS at the output's 16-byte phase, index the restart markers -----------------------------
+    // ---- index the restart markers --------------------------------------------------------------------------------
     const uint32_t al = base.x & 15u;
-    uint32_t o = al + ek;
-#pragma unroll
-    for (int r = 0; r < JD_K0_QUADS; r++)
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (keep[r][j >> 2] & (0x80u << ((j & 3) * 8))) buf[o++] = (uint8_t)(w[r][j >> 2] >> ((j & 3) * 8));
     if (nr) {                                                    // markers are rare: walk the set flags only
         uint32_t ridx = base.y + er, kb = base.x + ek;           // markers / kept bytes before the current quad
 #pragma unroll
@@ -235,20 +240,29 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
             }
         }
     }
-    __syncthreads();
-    // ---- LDS -> stream: whole 16-byte quads, bytes at the two ragged ends -------------------------------------
+    // (the barrier after the look-back also orders the compaction's LDS writes before the reads below)
+    // ---- LDS -> stream: whole 16-byte quads, bytes at the two ragged ends.  Output byte i of the aligned window
+    // (i = 0 at the 16-byte boundary below the chunk's first output byte) is buf[i - al] -------------------------------
     uint8_t* dst = a.stream + im.stream_off + JD_STREAM_FRONT + (base.x - al);   // 16-byte aligned
-    const uint32_t lo = al, hi = al + tk;                        // valid byte range in buf
+    const uint32_t lo = al, hi = al + tk;                        // valid byte range of the window
     const uint32_t qlo = (lo + 15u) >> 4, qhi = hi >> 4;         // whole quads [qlo, qhi)
-    for (uint32_t q = qlo + threadIdx.x; q < qhi; q += JD_K0_THREADS)
-        reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(buf)[q];
+    const uint32_t bsh = (0u - al) & 3u;                         // byte shift inside a dword (uniform)
+    for (uint32_t q = qlo + threadIdx.x; q < qhi; q += JD_K0_THREADS) {
+        const uint32_t p = q * 16u - al;                         // first source byte; five aligned dwords cover the 16
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(buf + (p & ~3u));
+        const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2], d3 = sp[3], d4 = sp[4];
+        uint4 v;
+        v.x = __builtin_amdgcn_alignbyte(d1, d0, bsh); v.y = __builtin_amdgcn_alignbyte(d2, d1, bsh);
+        v.z = __builtin_amdgcn_alignbyte(d3, d2, bsh); v.w = __builtin_amdgcn_alignbyte(d4, d3, bsh);
+        reinterpret_cast<uint4*>(dst)[q] = v;
+    }
     if (threadIdx.x < 32) {
         uint32_t i;
-        if (threadIdx.x < 16) { i = lo + threadIdx.x; if (i < hi && i < (qlo << 4)) dst[i] = buf[i]; }
+        if (threadIdx.x < 16) { i = lo + threadIdx.x; if (i < hi && i < (qlo << 4)) dst[i] = buf[i - al]; }
         else {
             uint32_t t1 = qhi << 4; if (t1 < (qlo << 4)) t1 = qlo << 4;
             i = t1 + (threadIdx.x - 16);
-            if (i >= lo && i < hi) dst[i] = buf[i];
+            if (i >= lo && i < hi) dst[i] = buf[i - al];
         }
     }
 }
