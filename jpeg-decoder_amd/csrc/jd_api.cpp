@@ -17,6 +17,9 @@
 #include "jd_internal.h"
 #include "jd_tables.h"
 
+// writer-table bytes that leave room for two writer workgroups on a CU (160 KiB of LDS)
+static const size_t kWriterLutTwoPerCu = (160 * 1024 / 2 - JD_W_WAVES * JD_WAVE_LDS) & ~(size_t)127;
+
 extern "C" {
 void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t wgs, hipStream_t s);
 void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
@@ -328,7 +331,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
                     else jd_pack_lut_multi(h.bits, h.vals, h.nvals, JD_SLUT_BITS, sset);
                     it = placed.emplace(cls * 4 + id, off).first;
                     wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
-                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, wset)) { delete b; return JD_E_TABLE; }
+                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_WIDE : JD_W32_DC_BITS, wset)) { delete b; return JD_E_TABLE; }
                     key.append((const char*)h.bits, 16); key.append((const char*)h.vals, h.nvals); key.push_back((char)(cls * 4 + id));
                 }
                 (cls ? im.ac_lut : im.dc_lut)[c] = it->second;
@@ -340,6 +343,21 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         }
         while (set.size() % 8) set.push_back(0);
         while (sset.size() % 8) sset.push_back(0);
+        im.w_ac_bits = JD_W32_AC_BITS_WIDE;
+        if (wset.size() * 4 > kWriterLutTwoPerCu) {               // too big for two writer workgroups per CU: narrow AC tables
+            wset.clear(); wplaced.clear();
+            for (int c = 0; c < f.ncomp; c++)
+                for (int cls = 0; cls < 2; cls++) {
+                    const int id = cls ? f.comp[c].ta : f.comp[c].td;
+                    if (!wplaced.count(cls * 4 + id)) {
+                        wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
+                        const jd_huff& h = f.huff[cls][id];
+                        if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_NARROW : JD_W32_DC_BITS, wset)) { delete b; return JD_E_TABLE; }
+                    }
+                    (cls ? im.wac : im.wdc)[c] = wplaced[cls * 4 + id];
+                }
+            im.w_ac_bits = JD_W32_AC_BITS_NARROW;
+        }
         while (wset.size() % 4) wset.push_back(0);
         auto sit = seen.find(key);
         if (sit == seen.end()) {

@@ -22,17 +22,19 @@
 // ---- writer tables (32-bit entries) ------------------------------------------------------------------
 // The whole-block writer decodes through its own tables, laid out so that the symbol step needs no left shifts
 // and almost no field extraction (on gfx950 right shifts, and/xor/add issue at twice the rate of left shifts,
-// bit-field extracts and three-operand forms).  One table = 2^JD_W32_BITS primary entries indexed by the next
-// JD_W32_BITS bits of the stream + 128-entry secondary tables indexed by the 7 bits after them.
+// bit-field extracts and three-operand forms).  One table = 2^P primary entries indexed by the next P bits of the
+// stream + 2^(16-P)-entry secondary tables indexed by the bits after them.
 //   bit 31 = 0 : [4:0]   32 - (code length + magnitude bits): how far to shift the window right to bring the
 //                        magnitude bits down -- a shift uses only these five bits, so the entry is the operand
 //                [15:8]  byte advance inside the block: 2 * (run + 1); 32 for ZRL; 254 for EOB; 0 for DC
 //                [30:16] magnitude mask 2^size - 1
 //   bit 31 = 1 : [30:0] offset (in entries, from the table start) of the secondary table
 //   0          : no code starts with these bits (invalid)
-#define JD_W32_BITS 9
-#define JD_W32_PRIMARY (1 << JD_W32_BITS)
-#define JD_W32_SECONDARY 128
+// primary index bits: DC tables 9; AC tables 10 when the set then still fits two writer workgroups per CU (a long
+// code costs the whole wave a second lookup), else 9.  Secondary tables are indexed by the 16 - primary following bits.
+#define JD_W32_DC_BITS 9
+#define JD_W32_AC_BITS_WIDE 10
+#define JD_W32_AC_BITS_NARROW 9
 #define JD_W32_EOB_ADV 254u
 
 // self-synchronising decode: bits per sub-sequence (one lane each)
@@ -97,6 +99,7 @@ struct JdImg {
     uint32_t w_off, w_len;       // writer tables (32-bit entries): u16 offset in the LUT buffer (16-byte aligned) and
                                  // length in entries (multiple of 4)
     uint32_t wdc[3], wac[3];     // per component: entry offset of its DC / AC writer table inside that set
+    uint32_t w_ac_bits;          // primary index bits of the AC writer tables
     uint32_t pad0;
     uint64_t stream_off;         // byte offset of this image's region in the unstuffed buffer
     uint64_t coef_off;           // int16 offset in the coefficient buffer

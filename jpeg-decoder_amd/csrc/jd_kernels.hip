@@ -379,11 +379,11 @@ __device__ __forceinline__ void la_st4(uint32_t addr, uint4 v) {
 
 // writer tables (32-bit entries, jd_internal.h): an invalid code reads as "one bit, end of block"
 #define JD_W32_SKIP (31u | (JD_W32_EOB_ADV << 8))
-__device__ __forceinline__ uint32_t w32_lookup(uint32_t tb, uint32_t win, uint32_t& bad) {
-    uint32_t e = la_u32(tb + ((win >> (30 - JD_W32_BITS)) & ((JD_W32_PRIMARY - 1u) << 2)));
+__device__ __forceinline__ uint32_t w32_lookup(uint32_t tb, uint32_t win, uint32_t bits, uint32_t& bad) {   // bits: wave-uniform
+    uint32_t e = la_u32(tb + ((win >> (30u - bits)) & (((1u << bits) - 1u) << 2)));
     if (__builtin_expect((int)e <= 0, 0)) {                        // secondary table, or no such code
         const uint32_t o = e & 0x7FFFFFFFu;
-        e = o ? la_u32(tb + (o << 2) + ((win >> (30 - JD_W32_BITS - 7)) & (127u << 2))) : 0u;
+        e = o ? la_u32(tb + (o << 2) + ((win >> 14) & ((0xFFFFu >> bits) << 2))) : 0u;   // the 16 - bits following bits
         if ((int)e <= 0) { bad = 1; e = JD_W32_SKIP; }
     }
     return e;
@@ -411,6 +411,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 #pragma unroll
     for (int i = 0; i < 4; i++) la_st4(slot_b + i * 16, make_uint4(0, 0, 0, 0));
     const uint32_t bpm = im.bpm, nl = im.hs * im.vs;
+    const uint32_t ac_bits = __builtin_amdgcn_readfirstlane(im.w_ac_bits);
     const uint32_t dc0 = lbase + im.wdc[0] * 4u, dc1 = lbase + im.wdc[1] * 4u, dc2 = lbase + im.wdc[2] * 4u;   // table addresses
     const uint32_t ac0 = lbase + im.wac[0] * 4u, ac1 = lbase + im.wac[1] * 4u, ac2 = lbase + im.wac[2] * 4u;
 
@@ -548,7 +549,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
             if (__builtin_amdgcn_ballot_w64(rpb >= wqb)) top_up_now();
             const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
-            e = w32_lookup(dcb, win, bad);
+            e = w32_lookup(dcb, win, JD_W32_DC_BITS, bad);
             const int diff = w32_value(win, e);
             advance(e, cand);
             const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
@@ -561,7 +562,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
             const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
-            e = w32_lookup(acb, win, bad);
+            e = w32_lookup(acb, win, ac_bits, bad);
             v = w32_value(win, e);
             advance(e, cand);
             o += (e >> 8) & 255u;
@@ -581,7 +582,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
             const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
-            e = w32_lookup(acb, win, bad);
+            e = w32_lookup(acb, win, ac_bits, bad);
             v = w32_value(win, e);
             advance(e, cand);
             o += (e >> 8) & 255u;

@@ -122,32 +122,33 @@ static inline uint32_t make_entry32(bool is_dc, unsigned sym, unsigned len) {
     return (32u - total) | (adv << 8) | (((1u << size) - 1u) << 16);
 }
 
-int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, std::vector<uint32_t>& out) {
+int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned prim_bits, std::vector<uint32_t>& out) {
+    const unsigned sec_bits = 16u - prim_bits;                   // a secondary table covers the rest of a 16-bit code
     int count = 0;
     for (int i = 0; i < 16; i++) count += bits[i];
     if (count != nvals || nvals > 256) return -1;
     const size_t base = out.size();
-    out.resize(base + JD_W32_PRIMARY, 0);
+    out.resize(base + (1u << prim_bits), 0);
     unsigned code = 0;
     int k = 0;
     for (unsigned len = 1; len <= 16; len++) {
         for (int i = 0; i < bits[len - 1]; i++, k++) {
             if (code >= (1u << len)) return -2;
             const uint32_t e = make_entry32(is_dc, vals[k], len);
-            if (len <= JD_W32_BITS) {
-                const unsigned first = code << (JD_W32_BITS - len), n = 1u << (JD_W32_BITS - len);
+            if (len <= prim_bits) {
+                const unsigned first = code << (prim_bits - len), n = 1u << (prim_bits - len);
                 for (unsigned j = 0; j < n; j++) out[base + first + j] = e;
             } else {
-                const unsigned prefix = code >> (len - JD_W32_BITS);
+                const unsigned prefix = code >> (len - prim_bits);
                 uint32_t p = out[base + prefix];
                 if (!(p & 0x80000000u)) {
                     if (p != 0) return -2;
                     const size_t off = out.size() - base;
-                    out.resize(out.size() + JD_W32_SECONDARY, 0);
+                    out.resize(out.size() + (1u << sec_bits), 0);
                     p = 0x80000000u | (uint32_t)off;
                     out[base + prefix] = p;
                 }
-                const unsigned sub = (code << (16 - len)) & 127u, n = 1u << (16 - len);
+                const unsigned sub = (code << (16 - len)) & ((1u << sec_bits) - 1u), n = 1u << (16 - len);
                 for (unsigned j = 0; j < n; j++) out[base + (p & 0x7FFFFFFFu) + sub + j] = e;
             }
             code++;

@@ -13,5 +13,5 @@ int jd_pack_lut(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_
 int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, unsigned lut_bits, std::vector<uint16_t>& out);
 // jd_pack_lut with a primary table of 2^lut_bits entries (the sync pass's tables are wider than the fallback ones)
 int jd_pack_lut_bits(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned lut_bits, std::vector<uint16_t>& out);
-// Writer table (32-bit entries, JD_W32_BITS-bit primary + 128-entry secondaries; layout in jd_internal.h).
-int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, std::vector<uint32_t>& out);
+// Writer table (32-bit entries, 2^prim_bits primary + 2^(16 - prim_bits)-entry secondaries; layout in jd_internal.h).
+int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned prim_bits, std::vector<uint32_t>& out);

@@ -35,9 +35,9 @@ static uint16_t look16(const std::vector<uint16_t>& t, uint32_t win, unsigned lu
     if (e & 0x8000u) e = (e & 0x7FFFu) ? t[(e & 0x7FFFu) + ((win >> (32 - lut_bits - 6)) & 63u)] : 0;
     return e;
 }
-static uint32_t look32(const std::vector<uint32_t>& t, uint32_t win) {
-    uint32_t e = t[win >> (32 - JD_W32_BITS)];
-    if (e & 0x80000000u) e = (e & 0x7FFFFFFFu) ? t[(e & 0x7FFFFFFFu) + ((win >> (32 - JD_W32_BITS - 7)) & 127u)] : 0;
+static uint32_t look32(const std::vector<uint32_t>& t, uint32_t win, unsigned pb) {
+    uint32_t e = t[win >> (32 - pb)];
+    if (e & 0x80000000u) e = (e & 0x7FFFFFFFu) ? t[(e & 0x7FFFFFFFu) + ((win >> 16) & (0xFFFFu >> pb))] : 0;
     return e;
 }
 
@@ -47,7 +47,8 @@ static void check_table(const char* name, const uint8_t bits[16], const uint8_t*
         std::vector<uint16_t> t16, tm;
         CHECK(jd_pack_lut_bits(bits, vals, nvals, is_dc, lb, t16) == 0, "%s pack16 bits %u", name, lb);
         std::vector<uint32_t> t32;
-        CHECK(jd_pack_lut32(bits, vals, nvals, is_dc, t32) == 0, "%s pack32", name);
+        const unsigned pb = lb == 12 ? 8 : lb == 11 ? 10 : 9;      // writer-table widths exercised: 9, 10, 8
+        CHECK(jd_pack_lut32(bits, vals, nvals, is_dc, pb, t32) == 0, "%s pack32", name);
         if (!is_dc) CHECK(jd_pack_lut_multi(bits, vals, nvals, lb, tm) == 0, "%s multi", name);
         for (const Code& c : codes) {
             const unsigned size = is_dc ? c.sym : (c.sym & 15u), run = c.sym >> 4;
@@ -59,7 +60,7 @@ static void check_table(const char* name, const uint8_t bits[16], const uint8_t*
                     if (c.len + size > 31) continue;
                     const uint32_t win = window(c, mag, size, fill);
                     const uint16_t e = look16(t16, win, lb);
-                    const uint32_t w = look32(t32, win);
+                    const uint32_t w = look32(t32, win, pb);
                     if (!valid) { CHECK(e == 0 && w == 0, "%s sym %02x should be invalid", name, c.sym); continue; }
                     CHECK((e & 31u) == c.len + size && ((e >> 5) & 15u) == size && ((e >> 9) & 63u) + 1 == adv,
                           "%s u16 sym %02x len %u: entry %04x", name, c.sym, c.len, e);
