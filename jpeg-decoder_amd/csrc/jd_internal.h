@@ -38,7 +38,9 @@
 #define JD_W32_EOB_ADV 254u
 
 // self-synchronising decode: bits per sub-sequence (one lane each)
+#ifndef JD_SUBSEQ_BITS
 #define JD_SUBSEQ_BITS 4096u
+#endif
 #define JD_SYNC_WG 256
 // The first JD_SYNC_WARM lanes of a sync workgroup re-decode the sub-sequences just before the ones the
 // workgroup owns, so that the owned lanes start from a state that has had >= JD_SYNC_WARM sub-sequences to

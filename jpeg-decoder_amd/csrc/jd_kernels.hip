@@ -143,7 +143,7 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
     __syncthreads();
     // ---- classify this thread's 64 contiguous bytes --------------------------------------------------------
     const uint32_t t0 = threadIdx.x * 16u * JD_K0_QUADS;         // byte offset inside the chunk
-    uint32_t w[JD_K0_QUADS][4], keep[JD_K0_QUADS][4], prevb[JD_K0_QUADS];
+    uint32_t w[JD_K0_QUADS][4], keep[JD_K0_QUADS][4], rstf[JD_K0_QUADS][4];
     uint32_t bad = 0, nk = 0, nr = 0;
 #pragma unroll
     for (int r = 0; r < JD_K0_QUADS; r++) {
@@ -156,11 +156,11 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
         const uint32_t prev = r ? (w[r - 1][3] >> 24) : (o ? raw[o - 1] : edge_prev);
         const uint32_t next = r + 1 < JD_K0_QUADS ? (w[r + 1][0] & 0xFFu) : (o + 16u < JD_K0_CHUNK ? raw[o + 16u] : edge_next);
         const uint32_t n = g < len ? (len - g < 16u ? len - g : 16u) : 0u;
-        uint32_t bq, rq[4];
-        k0_classify(w[r], prev, next, n, keep[r], rq, bq);
-        bad |= bq; prevb[r] = prev | (n << 8);
+        uint32_t bq;
+        k0_classify(w[r], prev, next, n, keep[r], rstf[r], bq);
+        bad |= bq;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { nk += __popc(keep[r][k]); nr += __popc(rq[k]); }
+        for (int k = 0; k < 4; k++) { nk += __popc(keep[r][k]); nr += __popc(rstf[r][k]); }
     }
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&a.status[img], JD_ST_MARKER);
     uint32_t tot;
@@ -221,11 +221,9 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
         uint32_t ridx = base.y + er, kb = base.x + ek;           // markers / kept bytes before the current quad
 #pragma unroll
         for (int r = 0; r < JD_K0_QUADS; r++) {
-            uint32_t kq[4], rq[4], bq;                           // marker flags are recomputed here, not kept live
-            k0_classify(w[r], prevb[r] & 0xFFu, 0xD9u, prevb[r] >> 8, kq, rq, bq);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                uint32_t f = rq[k];
+                uint32_t f = rstf[r][k];
                 while (f) {
                     const uint32_t bit = f & (0u - f);           // lowest marker byte of this dword (0x80 << 8j)
                     f ^= bit;
