@@ -222,13 +222,16 @@ int refresh(jd_batch* b, hipStream_t s) {
     // Both Huffman writers store whole blocks (zeros included): no coefficient range needs a zero-fill pass.
     b->clear_ranges.clear();
     const size_t pb = (size_t)(n + 1) * sizeof(uint32_t);
-    HIPCHK(hipMemcpyAsync(b->d_img, b->img.data(), (size_t)n * sizeof(JdImg), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_pre_k0, b->pre_k0.data(), pb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_pre_iv, b->pre_iv.data(), pb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_pre_sync, b->pre_sync.data(), pb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_pre_wr, b->pre_wr.data(), pb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b->d_pre_tile, b->pre_tile.data(), pb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));          // the host vectors may be rewritten by the next refresh
+    // Synchronous copies: the sources are pageable host memory, and hipMemcpyAsync from pageable memory followed by a
+    // stream synchronise was seen to leave part of a freshly allocated destination stale (about 1 % of one-shot decodes
+    // through jd_batch_upload_unstuffed; never with hipMemcpy).  These are set-up paths.
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(b->d_img, b->img.data(), (size_t)n * sizeof(JdImg), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_pre_k0, b->pre_k0.data(), pb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_pre_iv, b->pre_iv.data(), pb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_pre_sync, b->pre_sync.data(), pb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_pre_wr, b->pre_wr.data(), pb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_pre_tile, b->pre_tile.data(), pb, hipMemcpyHostToDevice));
     b->dirty = false;
     return JD_OK;
 }
@@ -445,8 +448,7 @@ extern "C" int jd_batch_upload(jd_batch* b, int image, const uint8_t* ecs, size_
     if (ecs_len == 0 || ecs_len > b->ecs_cap[image]) return JD_E_ARG;
     HIPCHK(hipSetDevice(b->device));
     uint8_t* dst = b->d_ecs_own + b->own_ecs_off[image];
-    HIPCHK(hipMemcpyAsync(dst, ecs, ecs_len, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));            // caller's buffer is free again on return (cgo rule)
+    HIPCHK(hipMemcpy(dst, ecs, ecs_len, hipMemcpyHostToDevice));   // synchronous (see refresh): caller's buffer is free again on return (cgo rule)
     JdImg& im = b->img[image];
     im.ecs = dst; im.ecs_len = (uint32_t)ecs_len; im.flags &= ~JD_IMG_UNSTUFFED_INPUT;
     b->dirty = true;
@@ -468,10 +470,9 @@ extern "C" int jd_batch_upload_unstuffed(jd_batch* b, int image, const uint8_t* 
     }
     HIPCHK(hipSetDevice(b->device));
     const uint32_t l32 = (uint32_t)len;
-    HIPCHK(hipMemcpyAsync(b->d_stream + im.stream_off + JD_STREAM_FRONT, bs, len, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_interval + im.interval_base, iv.data(), iv.size() * 4, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_stream_len + image, &l32, 4, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(b->d_stream + im.stream_off + JD_STREAM_FRONT, bs, len, hipMemcpyHostToDevice));   // synchronous (see refresh)
+    HIPCHK(hipMemcpy(b->d_interval + im.interval_base, iv.data(), iv.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_stream_len + image, &l32, 4, hipMemcpyHostToDevice));
     im.ecs_len = l32; im.flags |= JD_IMG_UNSTUFFED_INPUT;
     b->dirty = true;
     return JD_OK;
