@@ -520,8 +520,8 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
                 if (b < f_nblk[q]) {
                     jd_u32x4 t; t.x = f_hold[q].x; t.y = f_hold[q].y; t.z = f_hold[q].z; t.w = f_hold[q].w;
                     jd_u32x4* at = reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)b * 128u);
-                    // measured: streaming (non-temporal) stores take a quarter off the sub-sequence writer's time and add
-                    // 8 % to the restart-interval writer's
+                    // non-temporal: a plain store makes L2 fetch the line it is about to overwrite (FETCH_SIZE showed
+                    // one line read per line written -- 1.6 GB per 8 images); both writers use the streaming form
                     if (NT) __builtin_nontemporal_store(t, at); else *at = t;
                 }
             }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelAr
             sg.start_bit = b0 * 8u; sg.end_bit = b1 * 8u; sg.nblk = nm * im.bpm; sg.blk0 = iv * ri * im.bpm;
         }
     }
-    write_segments<false>(a, im, img, lut_bytes, sg, slen, err);
+    write_segments<true>(a, im, img, lut_bytes, sg, slen, err);
 }
 
 // ---- no-DRI path, pass 1: self-synchronising sub-sequences --------------------------------------------
