@@ -773,6 +773,10 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
 __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
     __shared__ uint32_t ex[JD_SYNC_WG];
     __shared__ uint32_t tmp[16];
+    // re-decode list and its results (gathered rounds): they live in wave 1's stream ring, idle while wave 0 alone decodes
+    uint32_t* const re_src = reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_RINGS + JD_SPEC_RING_BYTES);
+    uint32_t* const re_ent = re_src + 64;
+    uint32_t (*const re_out)[6] = reinterpret_cast<uint32_t (*)[6]>(re_src + 128);
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
@@ -817,9 +821,41 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
             else if (threadIdx.x > 0 && si > 0) ne = ex[threadIdx.x - 1];
         }
         const bool changed = active && ne != rec.entry;
-        if (!__syncthreads_or(changed)) break;
-        if (__builtin_amdgcn_ballot_w64(changed))                // wave-uniform: skip waves with nothing to redo
-            spec_decode<false>(ik, Q, qmax, a.lut + im.lut_off, s, ne, sbits, changed, rec);
+        const uint64_t bm = __builtin_amdgcn_ballot_w64(changed);
+        if ((threadIdx.x & 63u) == 0u) tmp[threadIdx.x >> 6] = (uint32_t)__popcll(bm);
+        __syncthreads();
+        const uint32_t n0 = tmp[0], n1 = tmp[1], n2 = tmp[2], n3 = tmp[3];
+        const uint32_t n = n0 + n1 + n2 + n3;
+        if (n == 0) break;
+        // After the first round only a few lanes per workgroup (the ones whose blind guess was wrong, then the
+        // ones after them) decode again: gathered into wave 0 they cost one wave's pass, not one per wave that
+        // holds any of them.
+        const bool gather = n <= 64u;                               // workgroup-uniform
+        const uint32_t wv = threadIdx.x >> 6;
+        const uint32_t pos = (wv > 0 ? n0 : 0u) + (wv > 1 ? n1 : 0u) + (wv > 2 ? n2 : 0u) +
+                             (uint32_t)__popcll(bm & ((1ull << (threadIdx.x & 63u)) - 1ull));
+        uint32_t s_x = s, e_x = ne; bool run_x = changed;
+        if (gather) {
+            if (changed) { re_src[pos] = s; re_ent[pos] = ne; }
+            __syncthreads();
+            run_x = threadIdx.x < n;
+            s_x = run_x ? re_src[threadIdx.x] : 0u;
+            e_x = run_x ? re_ent[threadIdx.x] : 0u;
+        }
+        JdSub r2 = rec;
+        if (__builtin_amdgcn_ballot_w64(run_x))                  // wave-uniform: skip waves with nothing to redo
+            spec_decode<false>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2);
+        if (gather) {
+            if (run_x) {
+                re_out[threadIdx.x][0] = r2.exit; re_out[threadIdx.x][1] = r2.nstart; re_out[threadIdx.x][2] = r2.first;
+                re_out[threadIdx.x][3] = (uint32_t)r2.dc[0]; re_out[threadIdx.x][4] = (uint32_t)r2.dc[1]; re_out[threadIdx.x][5] = (uint32_t)r2.dc[2];
+            }
+            __syncthreads();
+            if (changed) {
+                rec.entry = ne; rec.exit = re_out[pos][0]; rec.nstart = re_out[pos][1]; rec.first = re_out[pos][2];
+                rec.dc[0] = (int)re_out[pos][3]; rec.dc[1] = (int)re_out[pos][4]; rec.dc[2] = (int)re_out[pos][5];
+            }
+        } else if (changed) rec = r2;
     }
     if (owned) gsub[s] = rec;
     // workgroup totals for the spine scan
