@@ -103,7 +103,7 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    batch = args.batch or {"c3": 8, "c4": 4, "c5": 256}[args.workload]
+    batch = args.batch or {"c3": 16, "c4": 16, "c5": 1024}[args.workload]
     w, h, ri, files, distinct = make_images(args.workload, batch, rank, args.quality, args.detail)
 
     jd.init([local_rank])

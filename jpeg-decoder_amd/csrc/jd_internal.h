@@ -45,7 +45,9 @@
 // The first JD_SYNC_WARM lanes of a sync workgroup re-decode the sub-sequences just before the ones the
 // workgroup owns, so that the owned lanes start from a state that has had >= JD_SYNC_WARM sub-sequences to
 // synchronise and the cross-workgroup fix-up launches normally find nothing to redo.
+#ifndef JD_SYNC_WARM
 #define JD_SYNC_WARM 3
+#endif
 #define JD_SYNC_OWN (JD_SYNC_WG - JD_SYNC_WARM)
 
 // whole-block Huffman writer: waves per workgroup (they share the lookup tables) and LDS bytes per wave

@@ -655,6 +655,12 @@ __device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<
 // COLD = the first, blind decode: it starts JD_COLD_BITS before the END of the sub-sequence (its only product is
 // a guess of the exit state, and a guess made from the last stretch is as good as one made from all of it)
 // and skips the block-start bookkeeping.
+#ifndef JD_SYNC_ABL
+#define JD_SYNC_ABL 0                                             // timing ablations only (results are wrong)
+#endif
+#ifndef JD_SYNC_GATHER
+#define JD_SYNC_GATHER 128u                                      // most lanes a gathered re-decode round takes
+#endif
 #ifndef JD_COLD_BITS
 #define JD_COLD_BITS 2048u
 #endif
@@ -729,6 +735,8 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
             if (!COLD) {
                 if (nstart == 0) first = (uint32_t)left;                  // kept as "bits left" at that point
                 nstart++;
+                if (JD_SYNC_ABL & 8) { int dv = extend_bits(win, total, (e >> 5) & 15u); asm volatile("" :: "v"(dv)); }
+                else
                 atomicAdd(lds_int(csum), extend_bits(win, total, (e >> 5) & 15u));   // ds_add, no return
             }
             zn = 1;
@@ -773,10 +781,12 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
 __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
     __shared__ uint32_t ex[JD_SYNC_WG];
     __shared__ uint32_t tmp[16];
-    // re-decode list and its results (gathered rounds): they live in wave 1's stream ring, idle while wave 0 alone decodes
-    uint32_t* const re_src = reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_RINGS + JD_SPEC_RING_BYTES);
-    uint32_t* const re_ent = re_src + 64;
-    uint32_t (*const re_out)[6] = reinterpret_cast<uint32_t (*)[6]>(re_src + 128);
+    // re-decode list and its results (gathered rounds): they live in the last wave's stream ring, idle while the
+    // first JD_SYNC_GATHER / 64 waves decode
+    uint32_t* const re_src = reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_RINGS + (JD_SYNC_WG / 64u - 1u) * JD_SPEC_RING_BYTES);
+    uint32_t* const re_ent = re_src + JD_SYNC_GATHER;
+    uint32_t (*const re_out)[6] = reinterpret_cast<uint32_t (*)[6]>(re_src + 2u * JD_SYNC_GATHER);
+    static_assert(JD_SYNC_GATHER * 32u <= JD_SPEC_RING_BYTES && JD_SYNC_GATHER <= JD_SYNC_WG - 64u, "gather lists must fit an idle ring");
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     else {
         // blind decode: only its exit state is kept; entry 0 (not a valid state) makes every lane decode again
         // from its neighbour's exit in the first round of the loop below
-        spec_decode<true>(ik, Q, qmax, a.lut + im.lut_off, s, start_state, sbits, active && s != 0, rec);
+        if (!(JD_SYNC_ABL & 1)) spec_decode<true>(ik, Q, qmax, a.lut + im.lut_off, s, start_state, sbits, active && s != 0, rec);
         rec.entry = 0;
     }
     const uint32_t exit_before = rec.exit;
@@ -827,10 +837,12 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         const uint32_t n0 = tmp[0], n1 = tmp[1], n2 = tmp[2], n3 = tmp[3];
         const uint32_t n = n0 + n1 + n2 + n3;
         if (n == 0) break;
+        if ((JD_SYNC_ABL & 2) && it > 0) break;
+        if ((JD_SYNC_ABL & 4)) break;
         // After the first round only a few lanes per workgroup (the ones whose blind guess was wrong, then the
-        // ones after them) decode again: gathered into wave 0 they cost one wave's pass, not one per wave that
+        // ones after them) decode again: gathered into the first wave(s) they cost one wave's pass, not one per wave that
         // holds any of them.
-        const bool gather = n <= 64u;                               // workgroup-uniform
+        const bool gather = n <= JD_SYNC_GATHER;                    // workgroup-uniform
         const uint32_t wv = threadIdx.x >> 6;
         const uint32_t pos = (wv > 0 ? n0 : 0u) + (wv > 1 ? n1 : 0u) + (wv > 2 ? n2 : 0u) +
                              (uint32_t)__popcll(bm & ((1ull << (threadIdx.x & 63u)) - 1ull));
@@ -844,7 +856,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         }
         JdSub r2 = rec;
         if (__builtin_amdgcn_ballot_w64(run_x))                  // wave-uniform: skip waves with nothing to redo
-            spec_decode<false>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2);
+            spec_decode<(JD_SYNC_ABL & 16) != 0>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2);
         if (gather) {
             if (run_x) {
                 re_out[threadIdx.x][0] = r2.exit; re_out[threadIdx.x][1] = r2.nstart; re_out[threadIdx.x][2] = r2.first;
