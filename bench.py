@@ -5,9 +5,9 @@ One "step" = one pass of the whole hot path (unstuff + restart index, Huffman de
 chroma spread + colour) over one batch of synthetic JPEGs whose entropy-coded segments are already resident
 in HBM; outputs (RGB8) stay in HBM.  Workloads:
 
-  c3 (default)  8192x8192 4:2:0, Annex-K tables at quality 85, DRI every 8 MCUs, `--batch` images per GPU
-  c4            the same image(s) without restart markers (self-synchronising Huffman decode)
-  c5            `--batch` 1920x1080 4:2:0 images without restart markers
+  c3 (default)  8192x8192 4:2:0, Annex-K tables at quality 85, DRI every 8 MCUs, `--batch` images per GPU (16)
+  c4            the same images without restart markers (self-synchronising Huffman decode) (16)
+  c5            `--batch` 1920x1080 4:2:0 images without restart markers (1024)
 
 Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks
 time); every rank decodes its own images -- whole images shard with no data-path collective ("weak").
@@ -156,10 +156,10 @@ def main():
                     "huffman_write": "k1_write_subseq", "idct_colour": "k2_mcu_lanes"}
 
     def recorded_traffic(kernel):
-        """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_e_traffic.json), if they were
+        """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_f_traffic.json), if they were
         taken on this workload and batch; PMC counters cannot be read from inside this process."""
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_e_traffic.json")))["workloads"][args.workload]
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_f_traffic.json")))["workloads"][args.workload]
             if rec["batch"] != batch:
                 return None
             return rec["kernels"][kernel]["hbm_bytes_per_launch"]
