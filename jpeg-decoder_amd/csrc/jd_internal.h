@@ -56,8 +56,10 @@
 #define JD_WAVE_LDS (64u * 128u + 64u)
 
 // unstuff pass: bytes per workgroup
-#define JD_K0_THREADS 256
-#define JD_K0_CHUNK (JD_K0_THREADS * 64)
+#ifndef JD_K0_THREADS
+#define JD_K0_THREADS 512
+#endif
+#define JD_K0_CHUNK 16384
 
 // unstuffed stream: bytes of padding in front of / behind each image's data
 #define JD_STREAM_FRONT 16

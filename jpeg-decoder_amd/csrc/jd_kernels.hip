@@ -71,7 +71,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 // chunks before it (aggregate / inclusive-prefix in one 8-byte word, written and read with agent-scope
 // relaxed atomics -- the value and its tag travel together, so no fence is involved).  The ECS is read once
 // and the unstuffed stream written once.
-#define JD_K0_QUADS 4                                          // 16-byte quads per thread
+#define JD_K0_QUADS (JD_K0_CHUNK / (JD_K0_THREADS * 16))        // 16-byte quads per thread
 static_assert(JD_K0_CHUNK == JD_K0_THREADS * 16 * JD_K0_QUADS, "chunk size");
 
 __device__ __forceinline__ uint32_t zero_flags(uint32_t x) {   // 0x80 in every byte of x that is zero (exact)
