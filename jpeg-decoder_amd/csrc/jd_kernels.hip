@@ -106,7 +106,7 @@ __device__ __forceinline__ void k0_classify(const uint32_t (&w)[4], uint32_t pre
 #define JD_K0_AGG (1ull << 62)
 #define JD_K0_PFX (2ull << 62)
 
-__global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
+__global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a, uint32_t stride) {
     __shared__ uint32_t tmp[16];
     __shared__ uint32_t s_chunk;
     __shared__ uint2 s_base;
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a) {
     // blockIdx picks the image; the chunk inside it is the next ticket of THAT image (one counter for the whole
     // batch saturates at ~90 tickets/us -- measured 80 us for 7,200 chunks), so a chunk's predecessors have
     // always started before it
-    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    // Workgroups that are resident together should belong to different images (their tickets, status words and
+    // look-back chains are per image): blockIdx is spread over the images by a stride coprime to the grid size --
+    // any permutation will do, an image only needs as many workgroups as it has chunks.
+    const int img = find_image(a.prefix, a.n_images, (uint32_t)(((unsigned long long)blockIdx.x * stride) % gridDim.x));
     const JdImg& im = a.imgs[img];
     if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket + img, 1u);
     __syncthreads();
@@ -1377,7 +1380,11 @@ void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t 
     // ticket counter + per-chunk status words start at zero every run (memsets of >= 256 bytes on the stream)
     (void)hipMemsetAsync(a.k0_ticket, 0, (((size_t)a.n_images * 4) + 255) & ~(size_t)255, s);
     (void)hipMemsetAsync(a.k0_state, 0, ((size_t)wgs * 8 + 255) & ~(size_t)255, s);
-    hipLaunchKernelGGL(k0_unstuff, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x);
+    uint32_t stride = a.n_images > 1 ? wgs / (uint32_t)a.n_images : 1u;   // about one image's chunks
+    if (stride == 0) stride = 1;
+    auto gcd = [](uint32_t p, uint32_t q) { while (q) { const uint32_t t = p % q; p = q; q = t; } return p; };
+    while (gcd(stride, wgs) != 1u) stride++;
+    hipLaunchKernelGGL(k0_unstuff, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x, stride);
 }
 
 void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
