@@ -71,6 +71,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 // chunks before it (aggregate / inclusive-prefix in one 8-byte word, written and read with agent-scope
 // relaxed atomics -- the value and its tag travel together, so no fence is involved).  The ECS is read once
 // and the unstuffed stream written once.
+#ifndef JD_K0_WAVES_PER_SIMD
+#define JD_K0_WAVES_PER_SIMD 6
+#endif
 #define JD_K0_QUADS (JD_K0_CHUNK / (JD_K0_THREADS * 16))        // 16-byte quads per thread
 static_assert(JD_K0_CHUNK == JD_K0_THREADS * 16 * JD_K0_QUADS, "chunk size");
 
@@ -106,7 +109,7 @@ __device__ __forceinline__ void k0_classify(const uint32_t (&w)[4], uint32_t pre
 #define JD_K0_AGG (1ull << 62)
 #define JD_K0_PFX (2ull << 62)
 
-__global__ __launch_bounds__(JD_K0_THREADS) void k0_unstuff(JdKernelArgs a, uint32_t stride) {
+__global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuff(JdKernelArgs a, uint32_t stride) {
     __shared__ uint32_t tmp[16];
     __shared__ uint32_t s_chunk;
     __shared__ uint2 s_base;
