@@ -647,7 +647,9 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelAr
 // bursts a couple of hundred symbols apart.  Per sub-sequence it records the exit state, where the first
 // block starts, how many blocks start inside it and the sum of their DC differences per component -- what
 // the spine scan turns into block indices and DC predictors for the write pass (the DC prefix scan).
-#define JD_SPEC_RING_DW 16u                                   // ring depth in dwords (4 quads)
+#ifndef JD_SPEC_RING_DW
+#define JD_SPEC_RING_DW 8u                                    // ring depth in dwords (2 quads; 4 quads cost a workgroup per CU)
+#endif
 #define JD_SPEC_RING_BYTES (JD_SPEC_RING_DW * 256u)           // per wave: [dword][lane]
 
 // LDS map of k1_sync (byte offsets in dyn_lds)
@@ -787,12 +789,13 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
 __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
     __shared__ uint32_t ex[JD_SYNC_WG];
     __shared__ uint32_t tmp[16];
-    // re-decode list and its results (gathered rounds): they live in the last wave's stream ring, idle while the
+    // re-decode list and its results (gathered rounds): they live in the stream rings of the waves that idle while the
     // first JD_SYNC_GATHER / 64 waves decode
-    uint32_t* const re_src = reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_RINGS + (JD_SYNC_WG / 64u - 1u) * JD_SPEC_RING_BYTES);
+    constexpr uint32_t kGatherWaves = (JD_SYNC_GATHER + 63u) / 64u;
+    uint32_t* const re_src = reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_RINGS + kGatherWaves * JD_SPEC_RING_BYTES);
     uint32_t* const re_ent = re_src + JD_SYNC_GATHER;
     uint32_t (*const re_out)[6] = reinterpret_cast<uint32_t (*)[6]>(re_src + 2u * JD_SYNC_GATHER);
-    static_assert(JD_SYNC_GATHER * 32u <= JD_SPEC_RING_BYTES && JD_SYNC_GATHER <= JD_SYNC_WG - 64u, "gather lists must fit an idle ring");
+    static_assert(JD_SYNC_GATHER * 32u <= (JD_SYNC_WG / 64u - kGatherWaves) * JD_SPEC_RING_BYTES, "gather lists must fit the idle rings");
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     const uint32_t lw = blockIdx.x - a.prefix[img];
