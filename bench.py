@@ -156,10 +156,10 @@ def main():
                     "huffman_write": "k1_write_subseq", "idct_colour": "k2_mcu_lanes"}
 
     def recorded_traffic(kernel):
-        """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_f_traffic.json), if they were
+        """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_g_traffic.json), if they were
         taken on this workload and batch; PMC counters cannot be read from inside this process."""
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_f_traffic.json")))["workloads"][args.workload]
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_g_traffic.json")))["workloads"][args.workload]
             if rec["batch"] != batch:
                 return None
             return rec["kernels"][kernel]["hbm_bytes_per_launch"]
