@@ -67,7 +67,8 @@ enum {
     JD_E_TRUNCATED = -10,   /* entropy data ended before all MCUs were decoded (readBit -1, main.go:1273)  */
     JD_E_SYNC = -11,        /* internal: self-synchronising decode failed its consistency check          */
     JD_E_NOT_INIT = -12,
-    JD_E_STATE = -13        /* batch call out of order (e.g. wait before run)                            */
+    JD_E_STATE = -13,       /* batch call out of order (e.g. wait before run)                            */
+    JD_E_TOO_LARGE = -14    /* image does not fit a fixed-size workspace                                 */
 };
 const char* jd_strerror(int code);
 int jd_last_hip_error(void);
@@ -116,7 +117,8 @@ int jd_decode_coefficients(const jd_frame* frame, const uint8_t* ecs, size_t ecs
 typedef struct jd_batch jd_batch;
 
 enum {
-    JD_BATCH_KEEP_COEF = 1u   /* keep coefficients readable after run (jd_batch_coefficients)           */
+    JD_BATCH_KEEP_COEF = 1u,  /* keep coefficients readable after run (jd_batch_coefficients)           */
+    JD_BATCH_PINNED_IO = 2u   /* library-owned pinned staging + copy streams: jd_batch_stage_* / jd_batch_submit */
 };
 
 int jd_batch_create(int device, int n_images, const jd_frame* frames, const size_t* ecs_cap,
@@ -136,13 +138,36 @@ int jd_batch_bind_ecs(jd_batch* b, int image, const void* d_ecs, size_t ecs_len)
 int jd_batch_bind_rgb(jd_batch* b, int image, void* d_rgb, size_t row_stride);
 
 /* Enqueue the whole decode on `hip_stream` (a hipStream_t; NULL = the batch's own stream).  Does not
- * block and does not allocate. */
+ * allocate and does not wait for the device (descriptors go up by an asynchronous copy from pinned memory;
+ * it only waits if an earlier run of the same batch is still in flight on a DIFFERENT stream).
+ * Outputs are final once jd_batch_wait has returned: for images without restart markers the stream-ordered
+ * result is complete unless the self-synchronising pass needed more cross-workgroup fix-ups than the fixed
+ * number enqueued here (not observed; jd_batch_wait detects it, finishes the job and re-runs the consumers). */
 int jd_batch_run(jd_batch* b, void* hip_stream);
-/* Block until the last run finished; returns the first per-image error (or JD_OK). */
+/* Block until the last run (or submit) finished; returns the first per-image error (or JD_OK). */
 int jd_batch_wait(jd_batch* b);
 int jd_batch_status(const jd_batch* b, int image);
 int jd_batch_download(jd_batch* b, int image, uint8_t* rgb_out, size_t row_stride);
 int jd_batch_coefficients(jd_batch* b, int image, int16_t* coef_out, size_t coef_cap);
+
+/* ---- pinned-memory pipeline (the reference's file loop main.go:1509-1512 + writer
+ * main.go:1171-1218 in throughput form).  A batch created with JD_BATCH_PINNED_IO owns pinned host staging
+ * for the stuffed ECS of all its images and for all its RGB output, plus copy streams.  Per use:
+ *   jd_batch_stage_* for every image (the host writes / the library copies the ECS into the staging),
+ *   jd_batch_submit (asynchronous: one H2D copy -> the kernels -> one D2H copy, chained by events),
+ *   ... stage and submit OTHER batches meanwhile (two or three in flight keep both copy engines and the
+ *   CUs busy) ...
+ *   jd_batch_wait, then read the pixels in place through jd_batch_host_rgb.
+ * C-allocated memory throughout, so a Go caller may keep the pointers across calls (cgo pointer rule). */
+int jd_batch_stage_reserve(jd_batch* b, int image, size_t ecs_len, uint8_t** dst);   /* zero-copy: write ecs_len bytes at *dst */
+int jd_batch_stage_ecs(jd_batch* b, int image, const uint8_t* ecs, size_t ecs_len);  /* memcpy form                          */
+/* whole files: jd_parse + frame check against image first+k's frame + ECS copy, on `threads` host threads */
+int jd_batch_stage_jpegs(jd_batch* b, int first, int count, const uint8_t* const* files, const size_t* lens, int threads);
+int jd_batch_submit(jd_batch* b, void* hip_stream);
+int jd_batch_host_rgb(jd_batch* b, int image, const uint8_t** rgb, size_t* row_stride);
+/* Pinned host memory for callers that keep their own input/output buffers (hipHostMalloc / hipHostFree). */
+int jd_host_alloc(size_t bytes, void** out);
+void jd_host_free(void* p);
 
 /* Instrumentation for bench.py / DESIGN.md: runs `iters` decodes of the batch on its own stream and
  * returns, per pipeline stage, the average device time in microseconds measured with hipEvents around

@@ -42,6 +42,8 @@ ABI_SYMBOLS = [
     "jd_batch_upload", "jd_batch_upload_unstuffed", "jd_batch_bind_ecs", "jd_batch_bind_rgb", "jd_batch_run",
     "jd_batch_wait", "jd_batch_status", "jd_batch_download", "jd_batch_coefficients", "jd_batch_profile",
     "jd_batch_timing", "jd_batch_stage_times", "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
+    "jd_batch_stage_reserve", "jd_batch_stage_ecs", "jd_batch_stage_jpegs", "jd_batch_submit", "jd_batch_host_rgb",
+    "jd_host_alloc", "jd_host_free",
 ]
 
 
@@ -88,6 +90,14 @@ def _lib():
         L.jd_batch_workspace_bytes.argtypes = [_vp]
         L.jd_batch_workspace_bytes.restype = _sz
         L.jd_batch_unstuffed_len.argtypes = [_vp, _ci, ctypes.POINTER(_sz)]
+        L.jd_batch_stage_reserve.argtypes = [_vp, _ci, _sz, ctypes.POINTER(_vp)]
+        L.jd_batch_stage_ecs.argtypes = [_vp, _ci, _vp, _sz]
+        L.jd_batch_stage_jpegs.argtypes = [_vp, _ci, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _ci]
+        L.jd_batch_submit.argtypes = [_vp, _vp]
+        L.jd_batch_host_rgb.argtypes = [_vp, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]
+        L.jd_host_alloc.argtypes = [_sz, ctypes.POINTER(_vp)]
+        L.jd_host_free.argtypes = [_vp]
+        L.jd_host_free.restype = None
         L.jd_parse.argtypes = [_vp, _sz, PF, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
         L.jd_bmp_encode.argtypes = [_vp, _sz, _ci, _ci, _vp, _sz]
         L.jd_bmp_encode.restype = ctypes.c_long
@@ -189,14 +199,15 @@ def write_bitmap(rgb):
 class Batch:
     """jd_batch: n images decoded by one fixed sequence of batched kernels on one device."""
 
-    def __init__(self, frames, ecs_caps, device=0, keep_coef=False):
+    def __init__(self, frames, ecs_caps, device=0, keep_coef=False, pinned_io=False):
         _ensure_init()
         n = len(frames)
         self.n, self.device = n, device
         self.frames = (Frame * n)(*frames)
         caps = (_sz * n)(*[int(c) for c in ecs_caps])
         h = _vp()
-        _check(_lib().jd_batch_create(device, n, self.frames, caps, 1 if keep_coef else 0, ctypes.byref(h)), "jd_batch_create")
+        flags = (1 if keep_coef else 0) | (2 if pinned_io else 0)
+        _check(_lib().jd_batch_create(device, n, self.frames, caps, flags, ctypes.byref(h)), "jd_batch_create")
         self._h = h
 
     def close(self):
@@ -221,6 +232,33 @@ class Batch:
 
     def bind_rgb(self, i, dev_ptr, row_stride):
         _check(_lib().jd_batch_bind_rgb(self._h, i, dev_ptr, row_stride), "jd_batch_bind_rgb")
+
+    # ---- pinned-memory pipeline (JD_BATCH_PINNED_IO) ----
+    def stage_ecs(self, i, ecs):
+        a = _as_u8(ecs)
+        _check(_lib().jd_batch_stage_ecs(self._h, i, a.ctypes.data, a.size), "jd_batch_stage_ecs")
+
+    def stage_jpegs(self, files, first=0, threads=8):
+        """files: list of bytes / uint8 arrays holding whole JPEG files (kept alive by the caller during the call)"""
+        arrs = [_as_u8(f) for f in files]
+        ptrs = (_vp * len(arrs))(*[a.ctypes.data for a in arrs])
+        lens = (_sz * len(arrs))(*[a.size for a in arrs])
+        _check(_lib().jd_batch_stage_jpegs(self._h, first, len(arrs), ptrs, lens, threads), "jd_batch_stage_jpegs")
+
+    def stage_jpegs_raw(self, ptrs, lens, count, first=0, threads=8):
+        """the same with prepared ctypes arrays of file pointers / lengths (bench.py's timed host loop)"""
+        _check(_lib().jd_batch_stage_jpegs(self._h, first, count, ptrs, lens, threads), "jd_batch_stage_jpegs")
+
+    def submit(self, stream=None):
+        _check(_lib().jd_batch_submit(self._h, stream), "jd_batch_submit")
+
+    def host_rgb(self, i):
+        """-> H x W x 3 uint8 view of the pinned RGB staging (valid after wait(), until the next submit)"""
+        p, st = _vp(), _sz()
+        _check(_lib().jd_batch_host_rgb(self._h, i, ctypes.byref(p), ctypes.byref(st)), "jd_batch_host_rgb")
+        f = self.frames[i]
+        buf = (ctypes.c_uint8 * (st.value * f.height)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(f.height, f.width, 3)
 
     def run(self, stream=None):
         _check(_lib().jd_batch_run(self._h, stream), "jd_batch_run")
@@ -303,6 +341,7 @@ def _syn():
         S = ctypes.CDLL(SYNTH_PATH)
         S.jds_create.argtypes = [_ci] * 6 + [ctypes.c_uint64, _ci, ctypes.POINTER(_vp)]
         S.jds_encode.argtypes = [_vp, _ci, ctypes.POINTER(ctypes.POINTER(_u8)), ctypes.POINTER(_sz)]
+        S.jds_encode_ex.argtypes = [_vp, _ci, ctypes.c_uint, ctypes.POINTER(ctypes.POINTER(_u8)), ctypes.POINTER(_sz)]
         S.jds_destroy.argtypes = [_vp]
         S.jds_destroy.restype = None
         S.jds_free_buffer.argtypes = [ctypes.POINTER(_u8)]
@@ -336,9 +375,12 @@ class SynthImage:
         S.jds_coefficients(self._h, out.ctypes.data)
         return out
 
-    def encode(self, restart_interval=0):
+    SHARED_TABLES, ZERO_BASED_IDS, DQT_16BIT = 1, 2, 4
+
+    def encode(self, restart_interval=0, flags=0):
+        """flags: SHARED_TABLES (all components on Huffman tables 0/0), ZERO_BASED_IDS, DQT_16BIT (jd_synth.h)"""
         p, n = ctypes.POINTER(_u8)(), _sz()
-        rc = _syn().jds_encode(self._h, restart_interval, ctypes.byref(p), ctypes.byref(n))
+        rc = _syn().jds_encode_ex(self._h, restart_interval, flags, ctypes.byref(p), ctypes.byref(n))
         if rc:
             raise ValueError("jds_encode failed: %d" % rc)
         data = ctypes.string_at(p, n.value)

@@ -1,16 +1,19 @@
-// jd_api.cpp -- the C-ABI of include/jpeghip.h: frame validation, workspace planning, table upload and the
-// kernel sequence.  Host code only; the kernels are in jd_kernels.hip.
+// jd_api.cpp -- the C-ABI of include/jpeghip.h: frame validation, workspace planning, table upload, the kernel
+// sequence and the pinned-memory I/O pipeline.  Host code only; the kernels are in jd_kernels.hip.
 //
 // There is no CPU decode path in this library: every entry point that produces coefficients or pixels runs
 // the HIP kernels and fails with JD_E_HIP / JD_E_NOT_INIT when no device is usable.
 #include <hip/hip_runtime_api.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/jpeghip.h"
@@ -24,18 +27,15 @@ extern "C" {
 void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t wgs, hipStream_t s);
 void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
 void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
-                     int flag_slot, hipStream_t s);
+                     int flag_slot, int warm_off, hipStream_t s);
 void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
-void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t max_bpm,
-                            const JdIdctConst& K, hipStream_t s);
+void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
+void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, const JdIdctConst& K, hipStream_t s);
 }
 
 namespace {
 
-std::mutex g_mu;
-bool g_init = false;
-std::vector<int> g_devices;
 thread_local int g_last_hip = 0;
 
 #define HIPCHK(expr)                                                   \
@@ -46,10 +46,39 @@ thread_local int g_last_hip = 0;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- per-device state set up by jd_init ----------------------------------------------------------------
+struct DevCtx {
+    int device = -1;
+    uint8_t* scratch = nullptr; size_t scratch_bytes = 0;   // a fixed device block a batch can be built inside
+    uint8_t* pinned = nullptr; size_t pinned_bytes = 0;     // ... and the pinned host block that goes with it
+    hipStream_t stream = nullptr;
+};
+
+std::mutex g_mu;
+bool g_init = false;
+std::vector<std::unique_ptr<DevCtx>> g_ctx;
+
+DevCtx* find_ctx(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return nullptr;
+    for (auto& c : g_ctx) if (c->device == device) return c.get();
+    return nullptr;
+}
+
+void release_ctx_locked() {
+    for (auto& c : g_ctx) {
+        if (hipSetDevice(c->device) != hipSuccess) continue;
+        if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+        if (c->pinned) (void)hipHostFree(c->pinned);
+    }
+    g_ctx.clear();
+    g_init = false;
+}
+
 // ---- IDCT constants, main.go:1339-1354 ---------------------------------------------------------------
 // The Go binary computes them at init with its pure-Go math.Cos; the values below are those results (bit
-// patterns listed in SURVEY.md Appendix A.2, Go flavour).  tests/test_host_logic.py checks them against the
-// oracle's independent derivation.
+// patterns listed in SURVEY.md Appendix A.2, Go flavour).  tests/test_abi.py checks them against the oracle's
+// independent derivation.
 inline double from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 JdIdctConst idct_constants() {
     JdIdctConst K;
@@ -91,6 +120,11 @@ int frame_geometry(const jd_frame* f, Geometry* g) {
     return JD_OK;
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -105,11 +139,12 @@ extern "C" const char* jd_strerror(int code) {
     case JD_E_MARKER: return "Invalid marker found in the bitsteam";
     case JD_E_RESTART: return "Error! restart markers do not match the restart interval";
     case JD_E_HUFFMAN: return "Error! invalid DC Symbols";
-    case JD_E_COEF: return "Error! run/size walks past coefficient 63";
+    case JD_E_COEF: return "Error! run/size walks past coefficient 63, or a predicted DC leaves 16 bits";
     case JD_E_TRUNCATED: return "Error! EOF";
     case JD_E_SYNC: return "internal error: self-synchronising decode did not converge";
     case JD_E_NOT_INIT: return "jd_init has not been called or found no device";
     case JD_E_STATE: return "batch call out of order";
+    case JD_E_TOO_LARGE: return "image too large for a fixed workspace";
     default: return "unknown error";
     }
 }
@@ -123,12 +158,29 @@ extern "C" int jd_init(const int* device_ids, int n_devices) {
     std::vector<int> devs;
     if (!device_ids || n_devices <= 0) for (int i = 0; i < count; i++) devs.push_back(i);
     else for (int i = 0; i < n_devices; i++) { if (device_ids[i] < 0 || device_ids[i] >= count) return JD_E_ARG; devs.push_back(device_ids[i]); }
-    g_devices = devs;
+    if (g_init) {                                              // idempotent for the same device set
+        bool same = devs.size() == g_ctx.size();
+        for (size_t i = 0; same && i < devs.size(); i++) same = g_ctx[i]->device == devs[i];
+        if (same) return JD_OK;
+        release_ctx_locked();
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = JD_OK;
+    for (int d : devs) {
+        std::unique_ptr<DevCtx> c(new DevCtx());
+        c->device = d;
+        hipError_t he = hipSetDevice(d);
+        g_ctx.push_back(std::move(c));
+        if (he != hipSuccess) { g_last_hip = (int)he; rc = JD_E_HIP; break; }
+    }
     g_init = true;
-    return JD_OK;
+    if (rc != JD_OK) release_ctx_locked();
+    (void)hipSetDevice(prev);
+    return rc;
 }
-extern "C" void jd_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); g_init = false; g_devices.clear(); }
-extern "C" int jd_device_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_init ? (int)g_devices.size() : 0; }
+extern "C" void jd_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); int prev = 0; (void)hipGetDevice(&prev); release_ctx_locked(); (void)hipSetDevice(prev); }
+extern "C" int jd_device_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_init ? (int)g_ctx.size() : 0; }
 
 extern "C" int jd_frame_geometry(const jd_frame* f, uint32_t* mx, uint32_t* my, uint32_t* bpm) {
     Geometry g; int rc = frame_geometry(f, &g);
@@ -154,46 +206,82 @@ extern "C" int jd_frame_check(const jd_frame* f) {
     return JD_OK;
 }
 
+extern "C" int jd_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return JD_E_ARG;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { g_last_hip = (int)e; return e == hipErrorOutOfMemory ? JD_E_NOMEM : JD_E_HIP; }
+    return JD_OK;
+}
+extern "C" void jd_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 // ---------------------------------------------------------------------------------------------------
+// Where a batch's device workspace comes from: pieces of its own from hipMalloc, or slices of a fixed block (nothing
+// is allocated then; a request that does not fit fails).
+struct Arena {
+    uint8_t* base = nullptr; size_t cap = 0, used = 0;
+    std::vector<void*> owned;
+    size_t total = 0;
+    bool fixed() const { return base != nullptr; }
+    int take(void** p, size_t bytes) {
+        bytes = std::max<size_t>(align_up(bytes, 256), 256);
+        if (fixed()) {
+            if (used + bytes > cap) return JD_E_TOO_LARGE;
+            *p = base + used; used += bytes;
+        } else {
+            HIPCHK(hipMalloc(p, bytes));
+            owned.push_back(*p);
+        }
+        total += bytes;
+        return JD_OK;
+    }
+};
+
 struct jd_batch {
     int device = 0, n = 0;
     unsigned flags = 0;
     std::vector<jd_frame> frames;
-    std::vector<JdImg> img;                   // host mirror of d_img
+    std::vector<JdImg> img;                   // host mirror of the device descriptors
     std::vector<size_t> ecs_cap, own_ecs_off, own_rgb_off;
     std::vector<uint8_t> rgb_bound;
     std::vector<uint32_t> status;
+    Arena arena;
     // device memory
+    uint8_t* d_desc = nullptr;                // JdImg[n] + five workgroup prefixes, one block (one copy per refresh)
     JdImg* d_img = nullptr;
     uint8_t* d_ecs_own = nullptr; uint8_t* d_rgb_own = nullptr; uint8_t* d_stream = nullptr;
     int16_t* d_coef = nullptr; uint16_t* d_lut = nullptr;
     uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
     unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; JdSubPfx* d_subpfx = nullptr; uint4* d_sync_tot = nullptr;
     uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr;
-    std::vector<uint32_t> pre_k0, pre_iv, pre_sync, pre_wr, pre_tile;
-    std::vector<std::pair<size_t, size_t>> clear_ranges;   // coefficient ranges (int16 offset, count) that need zero-fill
-    size_t rgb_own_bytes = 0, stream_bytes = 0, coef_elems = 0, workspace = 0;
-    uint32_t max_lut_bytes = 0, max_w_bytes = 0, max_bpm = 1;
-    bool dirty = true, ran = false, any_dri = false, any_nodri = false;
+    // pinned host mirror of the descriptor block, followed by the read-back words (status per image, 64 sync flags)
+    uint8_t* h_desc = nullptr; size_t desc_bytes = 0, pre_stride = 0;
+    uint32_t *h_status = nullptr, *h_changed = nullptr;
+    bool own_pinned = false;
+    hipEvent_t ev_desc = nullptr; bool desc_in_flight = false;
+    size_t ecs_own_bytes = 0, rgb_own_bytes = 0, stream_bytes = 0, coef_elems = 0;
+    uint32_t max_lut_bytes = 0, max_w_bytes = 0;
+    uint32_t wg_k0 = 0, wg_iv = 0, wg_sync = 0, wg_wr = 0, wg_tile = 0;
+    bool dirty = true, ran = false, any_uniform = false;
     hipStream_t stream = nullptr, last_stream = nullptr;
+    bool own_stream = false;
     JdIdctConst K;
+    // pinned-memory I/O pipeline (JD_BATCH_PINNED_IO): library-owned staging for the stuffed ECS of every image and for
+    // the decoded RGB, copy streams and the events that chain H2D -> kernels -> D2H
+    uint8_t* h_ecs = nullptr; uint8_t* h_rgb = nullptr;
+    size_t staged_bytes = 0; int staged_count = 0; bool stage_open = false, io_pending = false;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_run = nullptr, ev_d2h = nullptr;
     // optional per-stage hipEvent timing of jd_batch_run (jd_batch_timing / jd_batch_stage_times)
     static const int kTimedRuns = 64;
     std::vector<hipEvent_t> events;           // kTimedRuns x (stages + 1)
     int timed_runs = 0;
     bool timing = false;
-    static const int kSyncFixups = 2;         // fix-up launches enqueued blindly; more only if the flag says so
+    int sync_fixups = 2;                      // fix-up launches enqueued blindly; jd_batch_wait adds more if the flag says so
+    int sync_warm_off = 0;                    // debug knob (JD_DEBUG_SYNC_NO_WARM)
 };
 
 namespace {
-
-template <class T>
-int dev_alloc(T** p, size_t count, size_t* total) {
-    const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-    HIPCHK(hipMalloc((void**)p, bytes));
-    *total += bytes;
-    return JD_OK;
-}
 
 JdKernelArgs kernel_args(const jd_batch* b) {
     JdKernelArgs a;
@@ -203,35 +291,38 @@ JdKernelArgs kernel_args(const jd_batch* b) {
     return a;
 }
 
-// recompute the per-kernel workgroup prefixes from the current ECS lengths and push descriptors
+// recompute the per-kernel workgroup prefixes from the current ECS lengths and push the descriptor block: host
+// mirror in pinned memory, one asynchronous copy on the stream the kernels will run on
 int refresh(jd_batch* b, hipStream_t s) {
     const int n = b->n;
-    b->pre_k0.assign(n + 1, 0); b->pre_iv.assign(n + 1, 0); b->pre_sync.assign(n + 1, 0); b->pre_wr.assign(n + 1, 0); b->pre_tile.assign(n + 1, 0);
+    // the pinned mirror is about to be rewritten: the copy that last read it must have run
+    if (b->desc_in_flight) {
+        if (b->ev_desc) HIPCHK(hipEventSynchronize(b->ev_desc)); else HIPCHK(hipStreamSynchronize(b->last_stream));
+        b->desc_in_flight = false;
+    }
+    // ... and a run still in flight on ANOTHER stream must not see its descriptors change under it
+    if (b->ran && b->last_stream != s) HIPCHK(hipStreamSynchronize(b->last_stream));
+    JdImg* himg = reinterpret_cast<JdImg*>(b->h_desc);
+    uint32_t* pre[5];
+    for (int k = 0; k < 5; k++) pre[k] = reinterpret_cast<uint32_t*>(b->h_desc + align_up((size_t)n * sizeof(JdImg), 256) + (size_t)k * b->pre_stride);
+    for (int k = 0; k < 5; k++) pre[k][0] = 0;
     for (int i = 0; i < n; i++) {
         JdImg& im = b->img[i];
         const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
         im.n_k0_chunks = stuffed ? (uint32_t)((im.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK) : 0;
         const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
         const uint32_t nsw = im.restart_interval ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_OWN - 1) / JD_SYNC_OWN);
-        b->pre_k0[i + 1] = b->pre_k0[i] + im.n_k0_chunks;
-        b->pre_iv[i + 1] = b->pre_iv[i] + (im.restart_interval ? (im.n_intervals + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES) : 0);
-        b->pre_sync[i + 1] = b->pre_sync[i] + nsw;
-        b->pre_wr[i + 1] = b->pre_wr[i] + (nsw * JD_SYNC_WG + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
-        b->pre_tile[i + 1] = b->pre_tile[i] + im.n_tiles;
+        pre[0][i + 1] = pre[0][i] + im.n_k0_chunks;
+        pre[1][i + 1] = pre[1][i] + (im.restart_interval ? (im.n_intervals + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES) : 0);
+        pre[2][i + 1] = pre[2][i] + nsw;
+        pre[3][i + 1] = pre[3][i] + (nsw * JD_SYNC_WG + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
+        pre[4][i + 1] = pre[4][i] + im.n_tiles;
+        himg[i] = im;
     }
-    // Both Huffman writers store whole blocks (zeros included): no coefficient range needs a zero-fill pass.
-    b->clear_ranges.clear();
-    const size_t pb = (size_t)(n + 1) * sizeof(uint32_t);
-    // Synchronous copies: the sources are pageable host memory, and hipMemcpyAsync from pageable memory followed by a
-    // stream synchronise was seen to leave part of a freshly allocated destination stale (about 1 % of one-shot decodes
-    // through jd_batch_upload_unstuffed; never with hipMemcpy).  These are set-up paths.
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipMemcpy(b->d_img, b->img.data(), (size_t)n * sizeof(JdImg), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_pre_k0, b->pre_k0.data(), pb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_pre_iv, b->pre_iv.data(), pb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_pre_sync, b->pre_sync.data(), pb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_pre_wr, b->pre_wr.data(), pb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_pre_tile, b->pre_tile.data(), pb, hipMemcpyHostToDevice));
+    b->wg_k0 = pre[0][n]; b->wg_iv = pre[1][n]; b->wg_sync = pre[2][n]; b->wg_wr = pre[3][n]; b->wg_tile = pre[4][n];
+    HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc, b->desc_bytes, hipMemcpyHostToDevice, s));
+    if (b->ev_desc) HIPCHK(hipEventRecord(b->ev_desc, s));
+    b->desc_in_flight = true; b->last_stream = s;
     b->dirty = false;
     return JD_OK;
 }
@@ -247,45 +338,53 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
     case ST_CLEAR:
         HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)n * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
-        for (const auto& r : b->clear_ranges) HIPCHK(hipMemsetAsync(b->d_coef + r.first, 0, r.second * sizeof(int16_t), s));
         break;
     case ST_UNSTUFF:
-        jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[n], s);
+        jdk_launch_k0(a, b->d_pre_k0, b->wg_k0, s);
         break;
     case ST_HUFF_DRI:
-        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[n], b->max_w_bytes, s);
+        jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, s);
         break;
     case ST_HUFF_SYNC:
-        if (b->pre_sync[n]) {
-            jdk_launch_sync(a, b->d_pre_sync, b->pre_sync[n], b->max_lut_bytes, 0, 0, s);
-            for (int k = 1; k <= jd_batch::kSyncFixups; k++)
-                jdk_launch_sync(a, b->d_pre_sync, b->pre_sync[n], b->max_lut_bytes, 1, k, s);
+        if (b->wg_sync) {
+            jdk_launch_sync(a, b->d_pre_sync, b->wg_sync, b->max_lut_bytes, 0, 0, b->sync_warm_off, s);
+            for (int k = 1; k <= b->sync_fixups; k++)
+                jdk_launch_sync(a, b->d_pre_sync, b->wg_sync, b->max_lut_bytes, 1, k, 0, s);
             jdk_launch_sync_spine(a, s);
         }
         break;
     case ST_HUFF_WRITE:
-        jdk_launch_write_subseq(a, b->d_pre_wr, b->pre_wr[n], b->max_w_bytes, s);
+        jdk_launch_write_subseq(a, b->d_pre_wr, b->wg_wr, b->max_w_bytes, s);
+        if (b->wg_wr && b->any_uniform) jdk_launch_dc_scan(a, s);
         break;
     case ST_IDCT_COLOUR:
-        jdk_launch_idct_colour(a, b->d_pre_tile, b->pre_tile[n], b->max_bpm, b->K, s);
+        jdk_launch_idct_colour(a, b->d_pre_tile, b->wg_tile, b->K, s);
         break;
     }
     HIPCHK(hipGetLastError());
     return JD_OK;
 }
 
-}  // namespace
+void batch_release(jd_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->own_stream && b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    for (hipStream_t s : { b->s_h2d, b->s_d2h }) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t e : { b->ev_desc, b->ev_h2d, b->ev_run, b->ev_d2h }) if (e) (void)hipEventDestroy(e);
+    for (void* p : b->arena.owned) (void)hipFree(p);
+    if (b->own_pinned && b->h_desc) (void)hipHostFree(b->h_desc);
+    if (b->h_ecs) (void)hipHostFree(b->h_ecs);
+    if (b->h_rgb) (void)hipHostFree(b->h_rgb);
+    for (auto& e : b->events) (void)hipEventDestroy(e);
+    delete b;
+}
 
-extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames, const size_t* ecs_cap,
-                               unsigned flags, jd_batch** out) {
-    if (!out) return JD_E_ARG;
+// Plans a batch and lays its workspace out.  dev == nullptr: a batch of its own (hipMalloc, pinned mirror, stream and
+// events created here).  dev != nullptr: everything lives in that context's fixed device and pinned blocks, the tables
+// go up asynchronously on `s`, and no allocating HIP call is made.
+int batch_build(int device, int n_images, const jd_frame* frames, const size_t* ecs_cap, unsigned flags, DevCtx* dev,
+                hipStream_t s, jd_batch** out) {
     *out = nullptr;
-    if (!frames || !ecs_cap || n_images <= 0) return JD_E_ARG;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_init) return JD_E_NOT_INIT;
-        if (std::find(g_devices.begin(), g_devices.end(), device) == g_devices.end()) return JD_E_ARG;
-    }
     for (int i = 0; i < n_images; i++) {
         int rc = jd_frame_check(&frames[i]);
         if (rc) return rc;
@@ -299,12 +398,15 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
     b->img.resize(n_images); b->ecs_cap.assign(ecs_cap, ecs_cap + n_images);
     b->own_ecs_off.resize(n_images); b->own_rgb_off.resize(n_images); b->rgb_bound.assign(n_images, 0);
     b->status.assign(n_images, 0);
+    b->sync_fixups = std::min(std::max(env_int("JD_SYNC_FIXUPS", 2), 0), 60);
+    b->sync_warm_off = env_int("JD_DEBUG_SYNC_NO_WARM", 0) ? 1 : 0;
+    if (dev) { b->arena.base = dev->scratch; b->arena.cap = dev->scratch_bytes; }
 
     // ---- Huffman table sets, de-duplicated across the batch -----------------------------------------
     std::vector<uint16_t> lut;
     std::map<std::string, std::pair<uint32_t, uint32_t>> seen;   // serialised tables -> (offset, length)
     size_t ecs_own = 0, rgb_own = 0, stream = 0, coef = 0;
-    uint32_t k0c = 0, ivb = 0, subb = 0, swb = 0, tileb = 0;
+    uint32_t k0c = 0, ivb = 0, subb = 0, swb = 0;
     for (int i = 0; i < n_images; i++) {
         const jd_frame& f = frames[i];
         JdImg& im = b->img[i];
@@ -314,27 +416,27 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         im.hs = g.hs; im.vs = g.vs; im.ncomp = f.ncomp; im.bpm = g.bpm;
         im.restart_interval = f.restart_interval;
         im.n_intervals = f.restart_interval ? (im.n_mcus + f.restart_interval - 1) / f.restart_interval : 1;
-        b->max_bpm = std::max(b->max_bpm, g.bpm);
-        if (f.restart_interval) b->any_dri = true; else b->any_nodri = true;
         // table set: per component (td, ta); identical (class,id) pairs share one packed table
         std::string key;
         std::vector<uint16_t> set, sset;                          // single-symbol tables / sync-pass twin (same layout)
         std::vector<uint32_t> wset;                               // writer tables (32-bit entries)
         std::map<int, uint32_t> placed, wplaced, splaced;         // class*4+id -> entry offset in set / wset / sset
+        bool uniform = f.ncomp > 1;
         for (int c = 0; c < f.ncomp; c++) {
+            if (f.comp[c].td != f.comp[0].td || f.comp[c].ta != f.comp[0].ta) uniform = false;
             for (int cls = 0; cls < 2; cls++) {
                 const int id = cls ? f.comp[c].ta : f.comp[c].td;
                 const jd_huff& h = f.huff[cls][id];
                 auto it = placed.find(cls * 4 + id);
                 if (it == placed.end()) {
                     const uint32_t off = (uint32_t)set.size();
-                    if (jd_pack_lut(h.bits, h.vals, h.nvals, cls == 0, set)) { delete b; return JD_E_TABLE; }
+                    if (jd_pack_lut(h.bits, h.vals, h.nvals, cls == 0, set)) { batch_release(b); return JD_E_TABLE; }
                     splaced.emplace(cls * 4 + id, (uint32_t)sset.size());
                     if (cls == 0) jd_pack_lut_bits(h.bits, h.vals, h.nvals, true, JD_SLUT_BITS, sset);
                     else jd_pack_lut_multi(h.bits, h.vals, h.nvals, JD_SLUT_BITS, sset);
                     it = placed.emplace(cls * 4 + id, off).first;
                     wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
-                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_WIDE : JD_W32_DC_BITS, wset)) { delete b; return JD_E_TABLE; }
+                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_WIDE : JD_W32_DC_BITS, wset)) { batch_release(b); return JD_E_TABLE; }
                     key.append((const char*)h.bits, 16); key.append((const char*)h.vals, h.nvals); key.push_back((char)(cls * 4 + id));
                 }
                 (cls ? im.ac_lut : im.dc_lut)[c] = it->second;
@@ -344,6 +446,10 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
             key.push_back((char)(0x40 | (f.comp[c].td << 2) | f.comp[c].ta));
             memcpy(im.q[c], f.qt[f.comp[c].tq], 64);
         }
+        // All components on one table pair (legal, rare): the entropy decoder's path through the stream does not depend
+        // on the block-in-MCU phase, so that phase never self-synchronises.  The no-DRI path then runs its sync pass
+        // without the phase and predicts DC in a pass of its own (k1_dc_scan).
+        if (uniform && f.restart_interval == 0) { im.flags |= JD_IMG_UNIFORM_TABLES; b->any_uniform = true; }
         while (set.size() % 8) set.push_back(0);
         while (sset.size() % 8) sset.push_back(0);
         im.w_ac_bits = JD_W32_AC_BITS_WIDE;
@@ -355,7 +461,7 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
                     if (!wplaced.count(cls * 4 + id)) {
                         wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
                         const jd_huff& h = f.huff[cls][id];
-                        if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_NARROW : JD_W32_DC_BITS, wset)) { delete b; return JD_E_TABLE; }
+                        if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_NARROW : JD_W32_DC_BITS, wset)) { batch_release(b); return JD_E_TABLE; }
                     }
                     (cls ? im.wac : im.wdc)[c] = wplaced[cls * 4 + id];
                 }
@@ -380,75 +486,202 @@ extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames,
         b->own_rgb_off[i] = rgb_own; rgb_own += align_up((size_t)f.width * 3 * f.height, 256);
         im.stream_off = stream; stream += align_up(JD_STREAM_FRONT + ecs_cap[i] + JD_STREAM_TAIL, 256);
         im.coef_off = coef; coef += (size_t)im.n_mcus * im.bpm * 64;
-        im.k0_chunk_base = k0c; k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);
+        k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);
         im.interval_base = ivb; ivb += im.n_intervals + 1;
         im.n_subseq_cap = (uint32_t)(((uint64_t)ecs_cap[i] * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
         im.n_sync_wg = f.restart_interval ? 0 : (im.n_subseq_cap + JD_SYNC_OWN - 1) / JD_SYNC_OWN;
         im.subseq_base = subb; subb += f.restart_interval ? 0 : im.n_sync_wg * JD_SYNC_OWN;
         im.sync_wg_base = swb; swb += im.n_sync_wg;
-        im.n_tiles = (im.n_mcus + JD_TILE_MCUS - 1) / JD_TILE_MCUS; im.tile_base = tileb; tileb += im.n_tiles;
+        im.n_tiles = (im.n_mcus + JD_TILE_MCUS - 1) / JD_TILE_MCUS;
         im.row_stride = (uint32_t)f.width * 3;
         im.ecs_len = 0;
     }
-    if (b->max_w_bytes > 160 * 1024 - JD_W_WAVES * JD_WAVE_LDS - 1024 || b->max_lut_bytes > 44 * 1024 /* sync pass: 64 KiB of LDS less its rings */) { delete b; return JD_E_TABLE; }
-    b->rgb_own_bytes = rgb_own; b->stream_bytes = stream; b->coef_elems = coef;
+    if (b->max_w_bytes > 160 * 1024 - JD_W_WAVES * JD_WAVE_LDS - 1024 || b->max_lut_bytes > 44 * 1024 /* sync pass: 64 KiB of LDS less its rings */) { batch_release(b); return JD_E_TABLE; }
+    b->ecs_own_bytes = ecs_own; b->rgb_own_bytes = rgb_own; b->stream_bytes = stream; b->coef_elems = coef;
 
-    size_t tot = 0;
+    // ---- descriptor block: JdImg[n], then five prefixes of n + 1 words; read-back words follow in the pinned mirror ----
+    const size_t img_bytes = align_up((size_t)n_images * sizeof(JdImg), 256);
+    b->pre_stride = align_up((size_t)(n_images + 1) * sizeof(uint32_t), 256);
+    b->desc_bytes = img_bytes + 5 * b->pre_stride;
+    const size_t lut_bytes = lut.size() * sizeof(uint16_t);
+    const size_t pinned_need = b->desc_bytes + align_up((size_t)n_images * 4, 256) + 256 + (dev ? align_up(lut_bytes, 256) : 0);
+
     int rc = JD_OK;
-    auto A = [&](int r) { if (rc == JD_OK) rc = r; };
-    A(dev_alloc(&b->d_img, (size_t)n_images, &tot));
-    A(dev_alloc(&b->d_ecs_own, ecs_own, &tot));
-    A(dev_alloc(&b->d_rgb_own, rgb_own, &tot));
-    A(dev_alloc(&b->d_stream, stream, &tot));
-    A(dev_alloc(&b->d_coef, coef, &tot));
-    A(dev_alloc(&b->d_lut, lut.size(), &tot));
-    A(dev_alloc(&b->d_status, (size_t)n_images, &tot));
-    A(dev_alloc(&b->d_stream_len, (size_t)n_images, &tot));
-    A(dev_alloc(&b->d_interval, (size_t)ivb, &tot));
-    A(dev_alloc(&b->d_changed, (size_t)64, &tot));
-    A(dev_alloc(&b->d_k0, (size_t)k0c + 32, &tot));
-    A(dev_alloc(&b->d_ticket, (size_t)n_images + 64, &tot));
-    A(dev_alloc(&b->d_sub, (size_t)subb, &tot));
-    A(dev_alloc(&b->d_subpfx, (size_t)subb, &tot));
-    A(dev_alloc(&b->d_sync_tot, (size_t)swb, &tot));
-    A(dev_alloc(&b->d_pre_k0, (size_t)n_images + 1, &tot));
-    A(dev_alloc(&b->d_pre_iv, (size_t)n_images + 1, &tot));
-    A(dev_alloc(&b->d_pre_sync, (size_t)n_images + 1, &tot));
-    A(dev_alloc(&b->d_pre_wr, (size_t)n_images + 1, &tot));
-    A(dev_alloc(&b->d_pre_tile, (size_t)n_images + 1, &tot));
-    if (rc == JD_OK && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) rc = JD_E_HIP;
-    if (rc == JD_OK && hipMemcpy(b->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) rc = JD_E_HIP;
-    if (rc == JD_OK && hipMemset(b->d_stream, 0, std::max<size_t>(stream, 256)) != hipSuccess) rc = JD_E_HIP;
-    if (rc != JD_OK) { jd_batch_destroy(b); return rc == JD_E_HIP && g_last_hip == (int)hipErrorOutOfMemory ? JD_E_NOMEM : rc; }
-    b->workspace = tot;
+    auto A = [&](void* pp, size_t bytes) { if (rc == JD_OK) rc = b->arena.take((void**)pp, bytes); };
+    A(&b->d_desc, b->desc_bytes);
+    if (!dev) {                                                   // a fixed-block batch reads and writes the caller's buffers only
+        A(&b->d_ecs_own, ecs_own);
+        A(&b->d_rgb_own, rgb_own);
+    }
+    A(&b->d_stream, stream);
+    A(&b->d_coef, coef * sizeof(int16_t));
+    A(&b->d_lut, lut_bytes);
+    A(&b->d_status, (size_t)n_images * 4);
+    A(&b->d_stream_len, (size_t)n_images * 4);
+    A(&b->d_interval, (size_t)ivb * 4);
+    A(&b->d_changed, 64 * 4);
+    A(&b->d_k0, ((size_t)k0c + 32) * 8);
+    A(&b->d_ticket, ((size_t)n_images + 64) * 4);
+    A(&b->d_sub, (size_t)subb * sizeof(JdSub));
+    A(&b->d_subpfx, (size_t)subb * sizeof(JdSubPfx));
+    A(&b->d_sync_tot, (size_t)swb * sizeof(uint4));
+    if (rc == JD_OK) {
+        b->d_img = reinterpret_cast<JdImg*>(b->d_desc);
+        uint32_t** pre[5] = { &b->d_pre_k0, &b->d_pre_iv, &b->d_pre_sync, &b->d_pre_wr, &b->d_pre_tile };
+        for (int k = 0; k < 5; k++) *pre[k] = reinterpret_cast<uint32_t*>(b->d_desc + img_bytes + (size_t)k * b->pre_stride);
+    }
+    if (rc == JD_OK) {
+        if (dev) {
+            if (pinned_need > dev->pinned_bytes) rc = JD_E_TOO_LARGE;
+            else { b->h_desc = dev->pinned; b->stream = s; }
+        } else {
+            if (hipHostMalloc((void**)&b->h_desc, pinned_need, hipHostMallocDefault) != hipSuccess) rc = JD_E_NOMEM;
+            else b->own_pinned = true;
+            if (rc == JD_OK && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) rc = JD_E_HIP;
+            else b->own_stream = true;
+            if (rc == JD_OK && hipEventCreateWithFlags(&b->ev_desc, hipEventDisableTiming) != hipSuccess) rc = JD_E_HIP;
+        }
+    }
+    if (rc == JD_OK) {
+        b->h_status = reinterpret_cast<uint32_t*>(b->h_desc + b->desc_bytes);
+        b->h_changed = reinterpret_cast<uint32_t*>(b->h_desc + b->desc_bytes + align_up((size_t)n_images * 4, 256));
+        memset(b->h_status, 0, (size_t)n_images * 4); memset(b->h_changed, 0, 256);
+    }
+    // ---- tables up, stream pads cleared.  Everything here is ordered on the batch's stream: the clear of the unstuffed-
+    // stream buffer used to be a hipMemset on the legacy stream, which the batch's non-blocking stream does not wait
+    // for, so a jd_batch_upload_unstuffed issued right after create could be overwritten by it (round 1's stale uploads).
+    if (rc == JD_OK) {
+        hipError_t he;
+        if (dev) {
+            uint8_t* hl = b->h_desc + pinned_need - align_up(lut_bytes, 256);
+            memcpy(hl, lut.data(), lut_bytes);
+            he = hipMemcpyAsync(b->d_lut, hl, lut_bytes, hipMemcpyHostToDevice, b->stream);
+        } else {
+            he = hipMemcpyAsync(b->d_lut, lut.data(), lut_bytes, hipMemcpyHostToDevice, b->stream);
+        }
+        if (he == hipSuccess) he = hipMemsetAsync(b->d_stream, 0, std::max<size_t>(stream, 256), b->stream);
+        if (he == hipSuccess && !dev) he = hipStreamSynchronize(b->stream);   // `lut` is pageable and goes out of scope
+        if (he != hipSuccess) { g_last_hip = (int)he; rc = JD_E_HIP; }
+    }
+    // ---- pinned I/O staging + copy streams -------------------------------------------------------------
+    if (rc == JD_OK && (flags & JD_BATCH_PINNED_IO)) {
+        if (dev) rc = JD_E_ARG;
+        else {
+            hipError_t he = hipHostMalloc((void**)&b->h_ecs, std::max<size_t>(ecs_own, 256), hipHostMallocDefault);
+            if (he == hipSuccess) he = hipHostMalloc((void**)&b->h_rgb, std::max<size_t>(rgb_own, 256), hipHostMallocDefault);
+            if (he == hipSuccess) he = hipStreamCreateWithFlags(&b->s_h2d, hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipStreamCreateWithFlags(&b->s_d2h, hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&b->ev_h2d, hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&b->ev_run, hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&b->ev_d2h, hipEventDisableTiming);
+            if (he != hipSuccess) { g_last_hip = (int)he; rc = he == hipErrorOutOfMemory ? JD_E_NOMEM : JD_E_HIP; }
+        }
+    }
+    if (rc != JD_OK) {
+        const bool oom = rc == JD_E_HIP && g_last_hip == (int)hipErrorOutOfMemory;
+        batch_release(b);
+        return oom ? JD_E_NOMEM : rc;
+    }
     for (int i = 0; i < n_images; i++) {
-        b->img[i].ecs = b->d_ecs_own + b->own_ecs_off[i];
-        b->img[i].rgb = b->d_rgb_own + b->own_rgb_off[i];
+        b->img[i].ecs = b->d_ecs_own ? b->d_ecs_own + b->own_ecs_off[i] : nullptr;
+        b->img[i].rgb = b->d_rgb_own ? b->d_rgb_own + b->own_rgb_off[i] : nullptr;
     }
     *out = b;
     return JD_OK;
 }
 
-extern "C" void jd_batch_destroy(jd_batch* b) {
-    if (!b) return;
-    (void)hipSetDevice(b->device);
-    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    void* ptrs[] = { b->d_img, b->d_ecs_own, b->d_rgb_own, b->d_stream, b->d_coef, b->d_lut, b->d_status, b->d_stream_len,
-                     b->d_interval, b->d_changed, b->d_k0, b->d_ticket, b->d_sub, b->d_subpfx, b->d_sync_tot, b->d_pre_k0, b->d_pre_iv, b->d_pre_sync, b->d_pre_wr,
-                     b->d_pre_tile };
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (auto& e : b->events) (void)hipEventDestroy(e);
-    delete b;
+int run_on(jd_batch* b, hipStream_t s) {
+    for (int i = 0; i < b->n; i++) if (b->img[i].ecs_len == 0 || !b->img[i].rgb) return JD_E_STATE;
+    if (b->dirty) { int rc = refresh(b, s); if (rc) return rc; }
+    else if (b->ran && b->last_stream != s) HIPCHK(hipStreamSynchronize(b->last_stream));   // one run at a time per workspace
+    const bool timed = b->timing && b->timed_runs < jd_batch::kTimedRuns;
+    hipEvent_t* ev = timed ? &b->events[(size_t)b->timed_runs * (ST_COUNT_ + 1)] : nullptr;
+    if (timed) HIPCHK(hipEventRecord(ev[0], s));
+    for (int st = 0; st < ST_COUNT_; st++) {
+        int rc = enqueue_stage(b, st, s); if (rc) return rc;
+        if (timed) HIPCHK(hipEventRecord(ev[st + 1], s));
+    }
+    if (timed) b->timed_runs++;
+    b->last_stream = s; b->ran = true;
+    return JD_OK;
 }
+
+int enqueue_rgb_download(jd_batch* b) {          // pipeline form: whole RGB staging in one copy behind the kernels
+    HIPCHK(hipEventRecord(b->ev_run, b->last_stream));
+    HIPCHK(hipStreamWaitEvent(b->s_d2h, b->ev_run, 0));
+    HIPCHK(hipMemcpyAsync(b->h_rgb, b->d_rgb_own, b->rgb_own_bytes, hipMemcpyDeviceToHost, b->s_d2h));
+    HIPCHK(hipEventRecord(b->ev_d2h, b->s_d2h));
+    return JD_OK;
+}
+
+// Blocks until the last run is complete and returns the first per-image error.  The self-synchronising pass carries
+// states across its workgroup boundaries with `sync_fixups` blind fix-up launches; if the last of them still moved a
+// boundary state (never seen with JD_SYNC_WARM warm-up sub-sequences; forced by tests/test_gpu_sync.py), the host keeps
+// launching fix-ups until nothing moves and re-runs the stages that consumed the result.
+int wait_on(jd_batch* b) {
+    hipStream_t s = b->last_stream;
+    if (b->io_pending) HIPCHK(hipEventSynchronize(b->ev_d2h));
+    HIPCHK(hipMemcpyAsync(b->h_changed, b->d_changed, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(b->h_status, b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    b->desc_in_flight = false;
+    const bool more = b->wg_sync && (b->sync_fixups == 0 || b->h_changed[b->sync_fixups]);
+    if (more) {
+        const JdKernelArgs a = kernel_args(b);
+        int guard = 0;
+        do {
+            HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
+            jdk_launch_sync(a, b->d_pre_sync, b->wg_sync, b->max_lut_bytes, 1, 1, 0, s);
+            HIPCHK(hipMemcpyAsync(b->h_changed, b->d_changed, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        } while (b->h_changed[1] && ++guard < 100000);
+        // status bits and everything downstream of the sync records are recomputed
+        HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));
+        jdk_launch_k0(a, b->d_pre_k0, b->wg_k0, s);             // restores K0's status bits (idempotent)
+        jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, s);
+        jdk_launch_sync_spine(a, s);
+        int rc = enqueue_stage(b, ST_HUFF_WRITE, s); if (rc) return rc;
+        rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
+        if (b->io_pending) { rc = enqueue_rgb_download(b); if (rc) return rc; }
+        HIPCHK(hipMemcpyAsync(b->h_status, b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (b->io_pending) HIPCHK(hipEventSynchronize(b->ev_d2h));
+    }
+    b->io_pending = false;
+    for (int i = 0; i < b->n; i++) b->status[i] = b->h_status[i];
+    for (int i = 0; i < b->n; i++) { int e = status_to_error(b->status[i]); if (e) return e; }
+    return JD_OK;
+}
+
+}  // namespace
+
+extern "C" int jd_batch_create(int device, int n_images, const jd_frame* frames, const size_t* ecs_cap,
+                               unsigned flags, jd_batch** out) {
+    if (!out) return JD_E_ARG;
+    *out = nullptr;
+    if (!frames || !ecs_cap || n_images <= 0) return JD_E_ARG;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_init) return JD_E_NOT_INIT;
+    }
+    if (!find_ctx(device)) return JD_E_ARG;
+    return batch_build(device, n_images, frames, ecs_cap, flags, nullptr, nullptr, out);
+}
+
+extern "C" void jd_batch_destroy(jd_batch* b) { batch_release(b); }
 
 static int check_image(const jd_batch* b, int image) { return (!b || image < 0 || image >= b->n) ? JD_E_ARG : JD_OK; }
 
+// Host-memory uploads: the source may be pageable, and the caller's buffer is free again on return (cgo rule), so these
+// enqueue on the batch's own stream and wait for it.
 extern "C" int jd_batch_upload(jd_batch* b, int image, const uint8_t* ecs, size_t ecs_len) {
     if (check_image(b, image) || !ecs) return JD_E_ARG;
     if (ecs_len == 0 || ecs_len > b->ecs_cap[image]) return JD_E_ARG;
+    if (!b->d_ecs_own) return JD_E_STATE;
     HIPCHK(hipSetDevice(b->device));
     uint8_t* dst = b->d_ecs_own + b->own_ecs_off[image];
-    HIPCHK(hipMemcpy(dst, ecs, ecs_len, hipMemcpyHostToDevice));   // synchronous (see refresh): caller's buffer is free again on return (cgo rule)
+    HIPCHK(hipMemcpyAsync(dst, ecs, ecs_len, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     JdImg& im = b->img[image];
     im.ecs = dst; im.ecs_len = (uint32_t)ecs_len; im.flags &= ~JD_IMG_UNSTUFFED_INPUT;
     b->dirty = true;
@@ -470,9 +703,10 @@ extern "C" int jd_batch_upload_unstuffed(jd_batch* b, int image, const uint8_t* 
     }
     HIPCHK(hipSetDevice(b->device));
     const uint32_t l32 = (uint32_t)len;
-    HIPCHK(hipMemcpy(b->d_stream + im.stream_off + JD_STREAM_FRONT, bs, len, hipMemcpyHostToDevice));   // synchronous (see refresh)
-    HIPCHK(hipMemcpy(b->d_interval + im.interval_base, iv.data(), iv.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_stream_len + image, &l32, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(b->d_stream + im.stream_off + JD_STREAM_FRONT, bs, len, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_interval + im.interval_base, iv.data(), iv.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_stream_len + image, &l32, 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     im.ecs_len = l32; im.flags |= JD_IMG_UNSTUFFED_INPUT;
     b->dirty = true;
     return JD_OK;
@@ -498,20 +732,8 @@ extern "C" int jd_batch_bind_rgb(jd_batch* b, int image, void* d_rgb, size_t row
 
 extern "C" int jd_batch_run(jd_batch* b, void* hip_stream) {
     if (!b) return JD_E_ARG;
-    for (int i = 0; i < b->n; i++) if (b->img[i].ecs_len == 0) return JD_E_STATE;
     HIPCHK(hipSetDevice(b->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
-    if (b->dirty) { int rc = refresh(b, s); if (rc) return rc; }
-    const bool timed = b->timing && b->timed_runs < jd_batch::kTimedRuns;
-    hipEvent_t* ev = timed ? &b->events[(size_t)b->timed_runs * (ST_COUNT_ + 1)] : nullptr;
-    if (timed) HIPCHK(hipEventRecord(ev[0], s));
-    for (int st = 0; st < ST_COUNT_; st++) {
-        int rc = enqueue_stage(b, st, s); if (rc) return rc;
-        if (timed) HIPCHK(hipEventRecord(ev[st + 1], s));
-    }
-    if (timed) b->timed_runs++;
-    b->last_stream = s; b->ran = true;
-    return JD_OK;
+    return run_on(b, hip_stream ? (hipStream_t)hip_stream : b->stream);
 }
 
 extern "C" int jd_batch_timing(jd_batch* b, int enable) {
@@ -544,34 +766,7 @@ extern "C" int jd_batch_wait(jd_batch* b) {
     if (!b) return JD_E_ARG;
     if (!b->ran) return JD_E_STATE;
     HIPCHK(hipSetDevice(b->device));
-    hipStream_t s = b->last_stream;
-    HIPCHK(hipStreamSynchronize(s));
-    uint32_t changed[64];
-    HIPCHK(hipMemcpy(changed, b->d_changed, sizeof changed, hipMemcpyDeviceToHost));
-    if (changed[jd_batch::kSyncFixups]) {
-        // Rare: a sub-sequence chain crossed more workgroup boundaries than the blind fix-ups cover.  Keep
-        // fixing up until no workgroup's exit state moves, then redo the stages that consumed the result.
-        const JdKernelArgs a = kernel_args(b);
-        int guard = 0;
-        do {
-            HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
-            jdk_launch_sync(a, b->d_pre_sync, b->pre_sync[b->n], b->max_lut_bytes, 1, 1, s);
-            HIPCHK(hipMemcpyAsync(changed, b->d_changed, sizeof changed, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-        } while (changed[1] && ++guard < 100000);
-        // clear only the sync-related status bits and the coefficients, then re-run the consumers
-        HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));
-        for (const auto& r : b->clear_ranges) HIPCHK(hipMemsetAsync(b->d_coef + r.first, 0, r.second * sizeof(int16_t), s));
-        jdk_launch_k0(a, b->d_pre_k0, b->pre_k0[b->n], s);          // restores K0 status bits (idempotent)
-        jdk_launch_intervals(a, b->d_pre_iv, b->pre_iv[b->n], b->max_w_bytes, s);
-        jdk_launch_sync_spine(a, s);
-        int rc = enqueue_stage(b, ST_HUFF_WRITE, s); if (rc) return rc;
-        rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(s));
-    }
-    HIPCHK(hipMemcpy(b->status.data(), b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (int i = 0; i < b->n; i++) { int e = status_to_error(b->status[i]); if (e) return e; }
-    return JD_OK;
+    return wait_on(b);
 }
 
 extern "C" int jd_batch_status(const jd_batch* b, int image) {
@@ -582,9 +777,10 @@ extern "C" int jd_batch_status(const jd_batch* b, int image) {
 extern "C" int jd_batch_download(jd_batch* b, int image, uint8_t* rgb_out, size_t row_stride) {
     if (check_image(b, image) || !rgb_out) return JD_E_ARG;
     const JdImg& im = b->img[image];
-    if (row_stride < (size_t)im.width * 3) return JD_E_ARG;
+    if (row_stride < (size_t)im.width * 3 || !im.rgb) return JD_E_ARG;
     HIPCHK(hipSetDevice(b->device));
-    HIPCHK(hipMemcpy2D(rgb_out, row_stride, im.rgb, im.row_stride, (size_t)im.width * 3, im.height, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2DAsync(rgb_out, row_stride, im.rgb, im.row_stride, (size_t)im.width * 3, im.height, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     return JD_OK;
 }
 
@@ -594,17 +790,19 @@ extern "C" int jd_batch_coefficients(jd_batch* b, int image, int16_t* out, size_
     const size_t n = (size_t)im.n_mcus * im.bpm * 64;
     if (cap < n) return JD_E_ARG;
     HIPCHK(hipSetDevice(b->device));
-    HIPCHK(hipMemcpy(out, b->d_coef + im.coef_off, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(out, b->d_coef + im.coef_off, n * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     return JD_OK;
 }
 
-extern "C" size_t jd_batch_workspace_bytes(const jd_batch* b) { return b ? b->workspace : 0; }
+extern "C" size_t jd_batch_workspace_bytes(const jd_batch* b) { return b ? b->arena.total : 0; }
 
 extern "C" int jd_batch_unstuffed_len(jd_batch* b, int image, size_t* len) {
     if (check_image(b, image) || !len) return JD_E_ARG;
     uint32_t v = 0;
     HIPCHK(hipSetDevice(b->device));
-    HIPCHK(hipMemcpy(&v, b->d_stream_len + image, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(&v, b->d_stream_len + image, 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     *len = v;
     return JD_OK;
 }
@@ -631,6 +829,93 @@ extern "C" int jd_batch_profile(jd_batch* b, int iters, float* stage_us, const c
     for (int st = 0; st < ST_COUNT_; st++) { stage_us[st] = (float)(acc[st] / iters); if (names) names[st] = kStageNames[st]; }
     b->last_stream = s; b->ran = true;
     return ST_COUNT_;
+}
+
+// ---- pinned-memory I/O pipeline ---------------------------------------------------------------
+// The reference reads one file, decodes it and writes one BMP, in turn (main.go:1509-1512).  In throughput form the
+// host keeps two or three JD_BATCH_PINNED_IO batches in flight: it fills one batch's pinned ECS staging (straight from
+// the files -- the staging IS the read buffer) while the device copies / decodes / copies back the others.
+static int stage_check(jd_batch* b) {
+    if (!b) return JD_E_ARG;
+    if (!(b->flags & JD_BATCH_PINNED_IO)) return JD_E_STATE;
+    if (b->io_pending) return JD_E_STATE;                    // a submit is in flight: jd_batch_wait first
+    if (!b->stage_open) { b->stage_open = true; b->staged_bytes = 0; b->staged_count = 0; for (auto& im : b->img) im.ecs_len = 0; }
+    return JD_OK;
+}
+
+extern "C" int jd_batch_stage_reserve(jd_batch* b, int image, size_t ecs_len, uint8_t** dst) {
+    int rc = stage_check(b); if (rc) return rc;
+    if (check_image(b, image) || !dst) return JD_E_ARG;
+    if (ecs_len == 0 || ecs_len > b->ecs_cap[image]) return JD_E_ARG;
+    if (b->img[image].ecs_len) return JD_E_STATE;            // staged twice
+    const size_t off = align_up(b->staged_bytes, 16);
+    if (off + ecs_len > b->ecs_own_bytes) return JD_E_ARG;
+    JdImg& im = b->img[image];
+    im.ecs = b->d_ecs_own + off; im.ecs_len = (uint32_t)ecs_len; im.flags &= ~JD_IMG_UNSTUFFED_INPUT;
+    im.rgb = b->d_rgb_own + b->own_rgb_off[image]; im.row_stride = im.width * 3; b->rgb_bound[image] = 0;
+    b->staged_bytes = off + ecs_len; b->staged_count++; b->dirty = true;
+    *dst = b->h_ecs + off;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_stage_ecs(jd_batch* b, int image, const uint8_t* ecs, size_t ecs_len) {
+    if (!ecs) return JD_E_ARG;
+    uint8_t* dst = nullptr;
+    int rc = jd_batch_stage_reserve(b, image, ecs_len, &dst); if (rc) return rc;
+    memcpy(dst, ecs, ecs_len);
+    return JD_OK;
+}
+
+// Parse `count` JPEG files held in memory (jd_parse, the twin of decodeJPEG's header work), check that file k matches
+// the frame image first + k was created with, and copy its entropy-coded segment into the staging; `threads` host
+// threads share the parsing and the copying.
+extern "C" int jd_batch_stage_jpegs(jd_batch* b, int first, int count, const uint8_t* const* files, const size_t* lens,
+                                    int threads) {
+    int rc = stage_check(b); if (rc) return rc;
+    if (!files || !lens || count <= 0 || first < 0 || first + count > b->n) return JD_E_ARG;
+    threads = std::max(1, std::min(threads, std::min(count, 64)));
+    std::vector<size_t> off(count), len(count);
+    std::vector<int> err(threads, JD_OK);
+    auto each = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++) pool.emplace_back([&, t] { for (int k = t; k < count; k += threads) fn(k, t); });
+        for (int k = 0; k < count; k += threads) fn(k, 0);
+        for (auto& th : pool) th.join();
+    };
+    each([&](int k, int t) {
+        jd_frame fr;
+        int r = files[k] ? jd_parse(files[k], lens[k], &fr, &off[k], &len[k]) : JD_E_ARG;
+        if (r == JD_OK && memcmp(&fr, &b->frames[first + k], sizeof fr) != 0) r = JD_E_ARG;   // not the frame the slot was planned for
+        if (r != JD_OK && err[t] == JD_OK) err[t] = r;
+    });
+    for (int e : err) if (e) return e;
+    std::vector<uint8_t*> dst(count);
+    for (int k = 0; k < count; k++) { rc = jd_batch_stage_reserve(b, first + k, len[k], &dst[k]); if (rc) return rc; }
+    each([&](int k, int) { memcpy(dst[k], files[k] + off[k], len[k]); });
+    return JD_OK;
+}
+
+extern "C" int jd_batch_submit(jd_batch* b, void* hip_stream) {
+    if (!b) return JD_E_ARG;
+    if (!(b->flags & JD_BATCH_PINNED_IO) || b->io_pending) return JD_E_STATE;
+    if (b->staged_count != b->n) return JD_E_STATE;          // every image staged (a finished staging may be re-submitted)
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+    HIPCHK(hipMemcpyAsync(b->d_ecs_own, b->h_ecs, b->staged_bytes, hipMemcpyHostToDevice, b->s_h2d));
+    HIPCHK(hipEventRecord(b->ev_h2d, b->s_h2d));
+    HIPCHK(hipStreamWaitEvent(s, b->ev_h2d, 0));
+    int rc = run_on(b, s); if (rc) return rc;
+    rc = enqueue_rgb_download(b); if (rc) return rc;
+    b->io_pending = true; b->stage_open = false;
+    return JD_OK;
+}
+
+extern "C" int jd_batch_host_rgb(jd_batch* b, int image, const uint8_t** rgb, size_t* row_stride) {
+    if (check_image(b, image) || !rgb) return JD_E_ARG;
+    if (!(b->flags & JD_BATCH_PINNED_IO) || b->io_pending) return JD_E_STATE;
+    *rgb = b->h_rgb + b->own_rgb_off[image];
+    if (row_stride) *row_stride = (size_t)b->img[image].width * 3;
+    return JD_OK;
 }
 
 // ---- one-shot forms ----------------------------------------------------------------------------------

@@ -110,6 +110,7 @@ extern "C" int jd_parse(const uint8_t* file, size_t file_len, jd_frame* fr, size
             }
         } else if (m == 0xDA) {                                                   // SOS
             if (!have_sof) return JD_E_MARKER;
+            if (r.i >= end) return JD_E_TRUNCATED;                                // empty SOS payload: nothing to read
             const int ns = r.u8();
             if (r.i + (size_t)ns * 2 + 3 > end) return JD_E_TRUNCATED;
             int used = 0;

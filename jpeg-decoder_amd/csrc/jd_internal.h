@@ -1,4 +1,4 @@
-// jd_internal.h -- shared between the host API (jd_api.hip) and the kernels (jd_kernels.hip).
+// jd_internal.h -- shared between the host API (jd_api.cpp) and the kernels (jd_kernels.hip).
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime_api.h>
@@ -80,7 +80,11 @@ enum {
     JD_ST_COUNT = 1u << 7        // decoded block count != expected
 };
 
-enum { JD_IMG_UNSTUFFED_INPUT = 1u };   // flags: K0 is skipped, host filled stream + interval table
+enum {
+    JD_IMG_UNSTUFFED_INPUT = 1u,   // K0 is skipped, host filled stream + interval table
+    JD_IMG_UNIFORM_TABLES = 2u     // every component uses the same DC and the same AC table: the sync pass ignores the
+                                   // block-in-MCU phase, the writer stores DC differences, k1_dc_scan predicts
+};
 
 struct JdImg {
     const uint8_t* ecs;          // stuffed ECS (device)
@@ -92,7 +96,7 @@ struct JdImg {
     uint32_t hs, vs, ncomp, bpm; // bpm = blocks per MCU
     uint32_t restart_interval, n_intervals;
     uint32_t flags;
-    uint32_t k0_chunk_base, n_k0_chunks;
+    uint32_t n_k0_chunks;
     uint32_t interval_base;      // index into interval_start[] (n_intervals + 1 entries)
     uint32_t subseq_base, n_subseq_cap, sync_wg_base, n_sync_wg;
     uint32_t lut_off, lut_len;   // u16 offset / length of this image's table set in the LUT buffer
@@ -106,7 +110,6 @@ struct JdImg {
                                  // length in entries (multiple of 4)
     uint32_t wdc[3], wac[3];     // per component: entry offset of its DC / AC writer table inside that set
     uint32_t w_ac_bits;          // primary index bits of the AC writer tables
-    uint32_t pad0;
     uint64_t stream_off;         // byte offset of this image's region in the unstuffed buffer
     uint64_t coef_off;           // int16 offset in the coefficient buffer
     uint8_t q[3][64];            // quantisation table per component, natural order
@@ -149,9 +152,3 @@ struct JdKernelArgs {
     uint32_t* changed;           // sync: set when a workgroup's exit state changed
 };
 
-// Launchers (jd_kernels.hip).  All are asynchronous on `stream`.
-struct JdLaunchPlan {
-    uint32_t k0_wgs, sync_wgs, interval_wgs, tile_wgs;
-    uint32_t max_lut_bytes;
-    int any_stuffed, any_dri, any_nodri;
-};

@@ -1,10 +1,13 @@
 // jd_kernels.hip -- CDNA4 (gfx950) kernels of the baseline-JPEG decode path.
 //
-//   K0  k0_count / k0_spine / k0_scatter   unstuff FF00, drop + index RSTn      (main.go:993-1021)
-//   K1  k1_sync / k1_sync_spine            self-synchronising sub-sequence pass (no DRI)
+//   K0  k0_unstuff                         unstuff FF00, drop + index RSTn, one pass with decoupled look-back
+//                                          (main.go:993-1021)
+//   K1  k1_sync / k1_sync_spine            self-synchronising sub-sequence pass + DC-prediction prefix scan (no DRI)
 //       k1_write_intervals / _subseq       Huffman decode -> int16 coefficients (main.go:749-816, 186-240,
 //                                          1156-1169, 1252-1316)
-//   K2  k2_idct_colour                     dequantise + de-zigzag + fp64 truncating IDCT + chroma spread +
+//       k1_dc_scan                         DC-prediction prefix scan as its own pass (images whose components all
+//                                          share one table pair: the block-in-MCU phase cannot self-synchronise)
+//   K2  k2_mcu_lanes                       dequantise + de-zigzag + fp64 truncating IDCT + chroma spread +
 //                                          float32 YCbCr->RGB (main.go:638-666, 454-606, 710-747, 669-707;
 //                                          zmap/map.go:3-68)
 //
@@ -17,9 +20,6 @@
 #include "jd_internal.h"
 
 #define WAVE 64
-#ifndef JD_K2_FORM
-#define JD_K2_FORM 1         // 1 = MCU per lane (no LDS, no barrier), 0 = block per lane with LDS exchange
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -399,9 +399,11 @@ __device__ __forceinline__ int w32_value(uint32_t win, uint32_t e) {
     return (int)raw - (int)(raw <= (e >> 17) ? m : 0u);            // e >> 17 = 2^(size-1) - 1
 }
 
+// raw_dc (wave-uniform): store each block's DC DIFFERENCE instead of the predicted value -- k1_dc_scan turns the
+// differences into predictions afterwards (images whose block-in-MCU phase cannot self-synchronise).
 template <bool NT>
 __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
-                                               const Segment& sg, uint32_t slen, uint32_t err) {
+                                               const Segment& sg, uint32_t slen, uint32_t err, bool raw_dc = false) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lbase = lds_abs_base();                               // multiple of 128 (dyn_lds is the kernel's only LDS)
@@ -444,6 +446,7 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     uint32_t npend = 0;
 
     int p0 = sg.p0, p1 = sg.p1, p2 = sg.p2;
+    const int keep = raw_dc ? 0 : -1;                                    // raw_dc: the predictors stay 0
     uint32_t c = sg.nblk ? sg.blk0 % bpm : 0u;
     uint32_t bad = 0;
     int16_t* const gbase = a.coef + im.coef_off;
@@ -557,7 +560,11 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
             const int diff = w32_value(win, e);
             advance(e, cand);
             const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
-            p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
+            const int pk = pred & keep;
+            p0 = comp == 0 ? pk : p0; p1 = comp == 1 ? pk : p1; p2 = comp >= 2 ? pk : p2;
+            // coefficients are held as int16 (the reference: int): a predicted DC outside it can only come from a
+            // damaged stream -- flagged, not wrapped silently
+            if (pred != (int)(short)pred) err |= JD_ST_COEF;
             la_st16(slot_b + rot, pred);   // coefficient 0: chunk 0 ^ (lane & 3)
             o = 0;
         }
@@ -663,9 +670,6 @@ __device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<
 // COLD = the first, blind decode: it starts JD_COLD_BITS before the END of the sub-sequence (its only product is
 // a guess of the exit state, and a guess made from the last stretch is as good as one made from all of it)
 // and skips the block-start bookkeeping.
-#ifndef JD_SYNC_ABL
-#define JD_SYNC_ABL 0                                             // timing ablations only (results are wrong)
-#endif
 #ifndef JD_SYNC_GATHER
 #define JD_SYNC_GATHER 128u                                      // most lanes a gathered re-decode round takes
 #endif
@@ -743,8 +747,6 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
             if (!COLD) {
                 if (nstart == 0) first = (uint32_t)left;                  // kept as "bits left" at that point
                 nstart++;
-                if (JD_SYNC_ABL & 8) { int dv = extend_bits(win, total, (e >> 5) & 15u); asm volatile("" :: "v"(dv)); }
-                else
                 atomicAdd(lds_int(csum), extend_bits(win, total, (e >> 5) & 15u));   // ds_add, no return
             }
             zn = 1;
@@ -786,7 +788,9 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
 
 // Workgroup w owns sub-sequences [w * JD_SYNC_OWN, (w + 1) * JD_SYNC_OWN); its lanes 0 .. JD_SYNC_WARM-1 warm up
 // on the JD_SYNC_WARM sub-sequences before them (results discarded).
-__global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot) {
+// warm_off (debug knob, JD_DEBUG_SYNC_NO_WARM): the warm-up lanes stay idle, so that every workgroup boundary depends on
+// the fix-up launches -- lets a test drive the host's extra fix-up loop.
+__global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot, int warm_off) {
     __shared__ uint32_t ex[JD_SYNC_WG];
     __shared__ uint32_t tmp[16];
     // re-decode list and its results (gathered rounds): they live in the stream rings of the waves that idle while the
@@ -803,7 +807,11 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     if (lw * JD_SYNC_OWN >= nsub) return;                       // whole workgroup past the stream (uniform)
-    const ImgK ik = load_imgk(im);
+    ImgK ik = load_imgk(im);
+    // every component decodes through the same table pair: the stream's path does not depend on the block-in-MCU
+    // phase, which therefore never self-synchronises -- the pass runs without it (one "component", c = 0) and the
+    // DC predictions come from k1_dc_scan instead of the per-component sums below
+    if (im.flags & JD_IMG_UNIFORM_TABLES) { ik.bpm = 1; ik.nl = 1; }
     if (threadIdx.x < 16u) {
         const uint32_t cc = threadIdx.x < ik.bpm ? threadIdx.x : 0u;
         const uint32_t comp = cc < ik.nl ? 0u : cc - ik.nl + 1u;
@@ -814,7 +822,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     const int si = (int)(lw * JD_SYNC_OWN + threadIdx.x) - JD_SYNC_WARM;
     const uint32_t s = si < 0 ? 0u : (uint32_t)si;
     const bool owned = threadIdx.x >= JD_SYNC_WARM && s < nsub;
-    const bool active = fixup ? owned : (si >= 0 && s < nsub);
+    const bool active = (fixup || warm_off) ? owned : (si >= 0 && s < nsub);
     const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
     const uint32_t qmax = (JD_STREAM_FRONT + slen + JD_STREAM_TAIL) / 16u - 1u;
     const uint32_t start_state = pack_state(0, 0, 0);
@@ -824,7 +832,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     else {
         // blind decode: only its exit state is kept; entry 0 (not a valid state) makes every lane decode again
         // from its neighbour's exit in the first round of the loop below
-        if (!(JD_SYNC_ABL & 1)) spec_decode<true>(ik, Q, qmax, a.lut + im.lut_off, s, start_state, sbits, active && s != 0, rec);
+        spec_decode<true>(ik, Q, qmax, a.lut + im.lut_off, s, start_state, sbits, active && s != 0, rec);
         rec.entry = 0;
     }
     const uint32_t exit_before = rec.exit;
@@ -846,8 +854,6 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         const uint32_t n0 = tmp[0], n1 = tmp[1], n2 = tmp[2], n3 = tmp[3];
         const uint32_t n = n0 + n1 + n2 + n3;
         if (n == 0) break;
-        if ((JD_SYNC_ABL & 2) && it > 0) break;
-        if ((JD_SYNC_ABL & 4)) break;
         // After the first round only a few lanes per workgroup (the ones whose blind guess was wrong, then the
         // ones after them) decode again: gathered into the first wave(s) they cost one wave's pass, not one per wave that
         // holds any of them.
@@ -865,7 +871,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         }
         JdSub r2 = rec;
         if (__builtin_amdgcn_ballot_w64(run_x))                  // wave-uniform: skip waves with nothing to redo
-            spec_decode<(JD_SYNC_ABL & 16) != 0>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2);
+            spec_decode<false>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2);
         if (gather) {
             if (run_x) {
                 re_out[threadIdx.x][0] = r2.exit; re_out[threadIdx.x][1] = r2.nstart; re_out[threadIdx.x][2] = r2.first;
@@ -930,6 +936,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs 
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     const uint32_t L = lw * (64u * JD_W_WAVES) + threadIdx.x;
     const uint32_t swg = L / JD_SYNC_WG, sl = L % JD_SYNC_WG;
+    const bool uniform = (im.flags & JD_IMG_UNIFORM_TABLES) != 0;
     if ((lw * (64u * JD_W_WAVES) / JD_SYNC_WG) * JD_SYNC_OWN >= nsub) return;   // whole workgroup past the stream
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
     const uint32_t s = swg * JD_SYNC_OWN + sl;
@@ -942,10 +949,10 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs 
         const uint4 base = a.sync_tot[im.sync_wg_base + swg];
         const uint32_t total_blocks = im.n_mcus * im.bpm;
         const uint32_t blk0 = base.x + pf.blk_off;
-        sg.p0 = (int)base.y + pf.dcp[0]; sg.p1 = (int)base.z + pf.dcp[1]; sg.p2 = (int)base.w + pf.dcp[2];
+        if (!uniform) { sg.p0 = (int)base.y + pf.dcp[0]; sg.p1 = (int)base.z + pf.dcp[1]; sg.p2 = (int)base.w + pf.dcp[2]; }
         sg.start_bit = s * JD_SUBSEQ_BITS + rec.first; sg.blk0 = blk0;
         sg.nblk = blk0 < total_blocks ? (rec.nstart < total_blocks - blk0 ? rec.nstart : total_blocks - blk0) : 0u;
-        if (sg.nblk) {
+        if (sg.nblk && !uniform) {
             // consistency of the scan with the sub-sequence's own state: the first block that starts here must
             // be the block-in-MCU the entry state implies
             const uint32_t c = (rec.entry >> 8) & 0xFFu, z = (rec.entry >> 16) & 0x7Fu;
@@ -954,15 +961,37 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs 
         }
         if (!sg.nblk) { sg.start_bit = 0; sg.blk0 = 0; }
     }
-    write_segments<true>(a, im, img, lut_bytes, sg, slen, err);
+    write_segments<true>(a, im, img, lut_bytes, sg, slen, err, uniform);
+}
+
+// ---- DC-prediction prefix scan as its own pass --------------------------------------------------------------
+// For images flagged JD_IMG_UNIFORM_TABLES (no DRI) the writer stored DC differences; one workgroup per (image,
+// component) walks that component's blocks in scan order and replaces each difference by the running sum
+// (prevDC, main.go:199-201, 750).
+__global__ __launch_bounds__(1024) void k1_dc_scan(JdKernelArgs a) {
+    __shared__ uint32_t tmp[16];
+    const int img = blockIdx.x / 3;
+    const uint32_t comp = blockIdx.x % 3;
+    const JdImg& im = a.imgs[img];
+    if (!(im.flags & JD_IMG_UNIFORM_TABLES) || im.restart_interval != 0 || comp >= im.ncomp) return;
+    const uint32_t nl = im.hs * im.vs, per = comp == 0 ? nl : 1u, n = im.n_mcus * per;
+    int16_t* const cf = a.coef + im.coef_off;
+    int carry = 0;
+    uint32_t bad = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 1024u) {
+        const uint32_t j = j0 + threadIdx.x;
+        const uint64_t blk = (uint64_t)(j / per) * im.bpm + (comp == 0 ? j % per : nl + comp - 1u);
+        const int d = j < n ? (int)cf[blk * 64u] : 0;
+        uint32_t tot;
+        const int v = carry + (int)block_excl_scan((uint32_t)d, tmp, tot) + d;
+        if (j < n) { cf[blk * 64u] = (int16_t)v; if (v != (int)(short)v) bad = 1; }
+        carry += (int)tot;
+    }
+    if (bad) atomicOr(&a.status[img], JD_ST_COEF);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2: dequantise + de-zigzag + IDCT + chroma spread + colour conversion
-// One workgroup = JD_TILE_MCUS consecutive MCUs; wave w handles block-in-MCU w of every MCU (one lane per
-// MCU), so the component -- and with it the quantisation table -- is wave-uniform.  The 8x8 block lives in
-// registers for both 1-D passes (no transpose traffic); samples go back to the block's own LDS slot as
-// int16; then all waves walk the tile's pixels, 4 per thread, and store packed RGB.
 // ------------------------------------------------------------------------------------------------
 struct ZZTables { int n2z[64]; };
 __host__ __device__ constexpr ZZTables make_zz() {
@@ -1004,160 +1033,6 @@ __device__ __forceinline__ uint32_t put_u8(float v, uint32_t sel, uint32_t old) 
 
 // (a variant that kept the column pass's truncated outputs in fp64 -- v_trunc_f64 instead of the
 // i32 round trip -- needs 156 VGPRs and measured 30 % slower on MI355X; the int form stays)
-
-#ifndef JD_K2_ABL
-#define JD_K2_ABL 0          // timing ablations only: 1 = no IDCT arithmetic, 2 = no colour arithmetic
-#endif
-// HS x VS luma blocks + (NC - 1) chroma blocks per MCU; all index arithmetic is compile-time.
-template <int HS, int VS, int NC>
-__device__ __forceinline__ void k2_body(const JdKernelArgs& a, const JdImg& im, uint32_t tile, const JdIdctConst& K,
-                                        uint2* origin) {
-    constexpr uint32_t NL = HS * VS, BPM = NL + NC - 1;
-    constexpr uint32_t MS = BPM * 128u + 16u;                      // LDS bytes per MCU (16 B pad: bank spread)
-    const uint32_t mcu0 = tile * JD_TILE_MCUS;
-    uint32_t nm = im.n_mcus - mcu0; if (nm > JD_TILE_MCUS) nm = JD_TILE_MCUS;
-    const uint32_t nthreads = blockDim.x;
-
-    // ---- stage the tile's coefficients: contiguous in HBM, 16 B per lane --------------------------
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(a.coef + im.coef_off + (uint64_t)mcu0 * BPM * 64u);
-        constexpr uint32_t per = BPM * 8u;
-        const uint32_t nchunks = nm * per;
-        for (uint32_t kx = threadIdx.x; kx < nchunks; kx += nthreads) {
-            const uint32_t m = kx / per, r = kx - m * per;
-            *reinterpret_cast<uint4*>(dyn_lds + m * MS + r * 16u) = src[kx];
-        }
-        if (threadIdx.x < JD_TILE_MCUS) {
-            const uint32_t M = mcu0 + threadIdx.x;
-            const uint32_t my = M / im.mcux, mx = M - my * im.mcux;
-            origin[threadIdx.x] = make_uint2(mx * 8u * HS, my * 8u * VS);
-        }
-    }
-    __syncthreads();
-
-    // ---- IDCT: wave = block-in-MCU, lane = MCU -------------------------------------------------------
-    {
-        const uint32_t bidx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const uint32_t m = threadIdx.x & 63u;
-        if (!(JD_K2_ABL & 1) && bidx < BPM && m < nm) {
-            const uint32_t comp = bidx < NL ? 0u : bidx - NL + 1u;
-            const uint8_t* __restrict__ q = im.q[comp];
-            uint8_t* slot = dyn_lds + m * MS + bidx * 128u;
-            uint32_t cw[32];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint4 v = *reinterpret_cast<const uint4*>(slot + i * 16);
-                cw[i * 4 + 0] = v.x; cw[i * 4 + 1] = v.y; cw[i * 4 + 2] = v.z; cw[i * 4 + 3] = v.w;
-            }
-            int mid[64];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                int x[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int zi = kZZ.n2z[r * 8 + j];
-                    const int cv = (zi & 1) ? ((int)cw[zi >> 1] >> 16) : (int)(short)(cw[zi >> 1] & 0xFFFFu);
-                    x[r] = __mul24(cv, (int)q[r * 8 + j]);          // dequantize, main.go:660-662
-                }
-                int o[8];
-                idct_1d(K, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
-#pragma unroll
-                for (int r = 0; r < 8; r++) mid[r * 8 + j] = o[r];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int o[8];
-                idct_1d(K, mid[i * 8 + 0], mid[i * 8 + 1], mid[i * 8 + 2], mid[i * 8 + 3], mid[i * 8 + 4], mid[i * 8 + 5],
-                        mid[i * 8 + 6], mid[i * 8 + 7], o);
-                // samples are held as saturated int16 (exact for every stream an 8-bit encoder can make)
-                typedef short short2v __attribute__((ext_vector_type(2)));
-                union { short2v s; uint32_t u; } p0, p1, p2, p3;
-                p0.s = __builtin_amdgcn_cvt_pk_i16(o[0], o[1]); p1.s = __builtin_amdgcn_cvt_pk_i16(o[2], o[3]);
-                p2.s = __builtin_amdgcn_cvt_pk_i16(o[4], o[5]); p3.s = __builtin_amdgcn_cvt_pk_i16(o[6], o[7]);
-                *reinterpret_cast<uint4*>(slot + i * 16) = make_uint4(p0.u, p1.u, p2.u, p3.u);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- colour: one row of one luma block (8 pixels, 24 bytes) per thread ---------------------------
-    // spreadCoeffecients (main.go:710-747): chroma sample of pixel (PX,PY) inside the MCU is element
-    // (PY>>1)*8 + (PX>>1) of the MCU's chroma block, whatever the sampling factors.
-    {
-        constexpr uint32_t ROWS = 8u * VS, ITEMS = ROWS * JD_TILE_MCUS * HS;
-        const uint32_t rs = im.row_stride;
-        uint8_t* const rgbp = im.rgb;
-        const bool al8 = ((rs & 7u) == 0) && ((reinterpret_cast<uintptr_t>(rgbp) & 7u) == 0);
-        for (uint32_t it = threadIdx.x; it < ITEMS; it += nthreads) {
-            const uint32_t bx = it % HS, m = (it / HS) % JD_TILE_MCUS, r = it / (HS * JD_TILE_MCUS);
-            if (m >= nm) continue;
-            const uint2 org = origin[m];
-            const uint32_t X = org.x + bx * 8u, Yp = org.y + r;
-            if (Yp >= im.height || X >= im.width) continue;
-            const uint8_t* mb = dyn_lds + m * MS;
-            const uint4 yv = *reinterpret_cast<const uint4*>(mb + ((r >> 3) * HS + bx) * 128u + (r & 7u) * 16u);
-            uint2 cbv = make_uint2(0, 0), crv = make_uint2(0, 0);
-            if (NC == 3) {
-                const uint32_t co = ((r >> 1) * 8u + bx * 4u) * 2u;
-                cbv = *reinterpret_cast<const uint2*>(mb + NL * 128u + co);
-                crv = *reinterpret_cast<const uint2*>(mb + (NL + 1u) * 128u + co);
-            }
-            const uint32_t yw[4] = { yv.x, yv.y, yv.z, yv.w };
-            const uint32_t cbw[2] = { cbv.x, cbv.y }, crw[2] = { crv.x, crv.y };
-            uint32_t d[6] = { 0, 0, 0, 0, 0, 0 };
-            if (JD_K2_ABL & 2) { d[0] = yw[0] ^ cbw[0]; d[1] = yw[1] ^ crw[0]; d[2] = yw[2] ^ cbw[1]; d[3] = yw[3] ^ crw[1]; }
-            else
-#pragma unroll
-            for (int k = 0; k < 4; k++) {                           // chroma sample k feeds pixels 2k, 2k+1
-                const int cbi = (k & 1) ? ((int)cbw[k >> 1] >> 16) : (int)(short)(cbw[k >> 1] & 0xFFFFu);
-                const int cri = (k & 1) ? ((int)crw[k >> 1] >> 16) : (int)(short)(crw[k >> 1] & 0xFFFFu);
-                const float cb = (float)cbi, cr = (float)cri;
-                const float rc = __fmul_rn(1.402f, cr), gb = __fmul_rn(0.344f, cb), gr = __fmul_rn(0.714f, cr);
-                const float bc = __fmul_rn(1.772f, cb);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int j = 2 * k + h;
-                    const int yi = h ? ((int)yw[k] >> 16) : (int)(short)(yw[k] & 0xFFFFu);
-                    const float y = (float)yi;
-                    const float R = __fadd_rn(__fadd_rn(y, rc), 128.0f);
-                    const float G = __fadd_rn(__fsub_rn(__fsub_rn(y, gb), gr), 128.0f);
-                    const float B = __fadd_rn(__fadd_rn(y, bc), 128.0f);
-                    d[(3 * j) >> 2] = put_u8(R, (3 * j) & 3, d[(3 * j) >> 2]);
-                    d[(3 * j + 1) >> 2] = put_u8(G, (3 * j + 1) & 3, d[(3 * j + 1) >> 2]);
-                    d[(3 * j + 2) >> 2] = put_u8(B, (3 * j + 2) & 3, d[(3 * j + 2) >> 2]);
-                }
-            }
-            uint8_t* dst = rgbp + (uint64_t)Yp * rs + X * 3u;
-            if (al8 && X + 8u <= im.width) {
-                uint2* o = reinterpret_cast<uint2*>(dst);
-                o[0] = make_uint2(d[0], d[1]); o[1] = make_uint2(d[2], d[3]); o[2] = make_uint2(d[4], d[5]);
-            } else {
-                const uint32_t n = im.width - X < 8u ? im.width - X : 8u;
-#pragma unroll
-                for (uint32_t k = 0; k < 24; k++)
-                    if (k < n * 3u) dst[k] = (uint8_t)(d[k >> 2] >> ((k & 3u) * 8u));
-            }
-        }
-    }
-}
-
-#ifndef JD_K2_WPS
-#define JD_K2_WPS 4
-#endif
-__global__ __launch_bounds__(384, JD_K2_WPS) void k2_idct_colour(JdKernelArgs a, JdIdctConst K) {
-    __shared__ uint2 origin[JD_TILE_MCUS];                        // pixel origin of each MCU of the tile
-    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
-    const JdImg& im = a.imgs[img];
-    const uint32_t tile = blockIdx.x - a.prefix[img];
-    const uint32_t mode = im.ncomp == 1 ? 0u : im.hs + 2u * im.vs - 2u;   // 1: 1x1, 2: 2x1, 3: 1x2, 4: 2x2
-    switch (mode) {                                                // wave-uniform
-    case 0: k2_body<1, 1, 1>(a, im, tile, K, origin); break;
-    case 1: k2_body<1, 1, 3>(a, im, tile, K, origin); break;
-    case 2: k2_body<2, 1, 3>(a, im, tile, K, origin); break;
-    case 3: k2_body<1, 2, 3>(a, im, tile, K, origin); break;
-    default: k2_body<2, 2, 3>(a, im, tile, K, origin); break;
-    }
-}
 
 // ---- K2, MCU-per-lane form -----------------------------------------------------------------------------
 // One lane owns one whole MCU, one wave owns 64 consecutive MCUs; waves never talk to each other: no LDS, no
@@ -1236,8 +1111,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 const int qv = (int)((qw[(r * 8 + j) >> 2] >> (((r * 8 + j) & 3) * 8)) & 0xFFu);
                 x[r] = __mul24(cv, qv);                             // dequantize, main.go:660-662
             }
-            if (JD_K2_ABL & 1) { for (int r = 0; r < 8; r++) o[r] = x[r]; }
-            else idct_1d(K, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
+            idct_1d(K, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
 #pragma unroll
             for (int r = 0; r < 8; r++) mid[r * 8 + j] = o[r];
         }
@@ -1245,8 +1119,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             int o[8];
-            if (JD_K2_ABL & 1) { for (int r = 0; r < 8; r++) o[r] = mid[i * 8 + r]; }
-            else idct_1d(K, mid[i * 8 + 0], mid[i * 8 + 1], mid[i * 8 + 2], mid[i * 8 + 3], mid[i * 8 + 4], mid[i * 8 + 5],
+            idct_1d(K, mid[i * 8 + 0], mid[i * 8 + 1], mid[i * 8 + 2], mid[i * 8 + 3], mid[i * 8 + 4], mid[i * 8 + 5],
                     mid[i * 8 + 6], mid[i * 8 + 7], o);
             typedef short short2v __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -1310,8 +1183,6 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 const int i = 2 * r + h;
                 const uint32_t Yp = Y0 + by * 8u + (uint32_t)i;
                 uint32_t d[6] = { 0, 0, 0, 0, 0, 0 };
-                if (JD_K2_ABL & 2) { d[0] = smp[i * 4] ^ cq[0][r * 2]; d[1] = smp[i * 4 + 1] ^ cq[1][r * 2]; d[2] = smp[i * 4 + 2] ^ cq[0][r * 2 + 1]; d[3] = smp[i * 4 + 3] ^ cq[1][r * 2 + 1]; }
-                else
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     // the two pixels that share chroma sample k, as one packed-f32 pair: the same additions in the same
@@ -1404,16 +1275,20 @@ void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint3
 }
 
 void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
-                     int flag_slot, hipStream_t s) {
+                     int flag_slot, int warm_off, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 15u) & ~15u;
     const uint32_t lds = JD_SY_LUT + lb;
-    hipLaunchKernelGGL(k1_sync, dim3(wgs), dim3(JD_SYNC_WG), lds, s, x, fixup, flag_slot);
+    hipLaunchKernelGGL(k1_sync, dim3(wgs), dim3(JD_SYNC_WG), lds, s, x, fixup, flag_slot, warm_off);
 }
 
 void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k1_sync_spine, dim3(a.n_images), dim3(256), 0, s, a);
+}
+
+void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k1_dc_scan, dim3(a.n_images * 3), dim3(1024), 0, s, a);
 }
 
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
@@ -1426,17 +1301,10 @@ void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, ui
     hipLaunchKernelGGL(k1_write_subseq, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
-void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t max_bpm,
-                            const JdIdctConst& K, hipStream_t s) {
+void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, const JdIdctConst& K, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
-    const uint32_t lds = JD_TILE_MCUS * (max_bpm * 128u + 16u);
-#if JD_K2_FORM == 1
-    (void)lds;
     hipLaunchKernelGGL(k2_mcu_lanes, dim3(wgs), dim3(64), 8192 + 8 * 1536, s, x, K);
-#else
-    hipLaunchKernelGGL(k2_idct_colour, dim3(wgs), dim3(64 * max_bpm), lds, s, x, K);
-#endif
 }
 
 }  // extern "C"

@@ -287,6 +287,12 @@ static void put_dht(bitw* w, int tc_th, const uint8_t* bits, const uint8_t* vals
 }
 
 int jds_encode(const jds_image* im, int restart_interval, uint8_t** out, size_t* out_len) {
+    return jds_encode_ex(im, restart_interval, 0, out, out_len);
+}
+
+int jds_encode_ex(const jds_image* im, int restart_interval, unsigned flags, uint8_t** out, size_t* out_len) {
+    const int shared = (flags & JDS_SHARED_TABLES) != 0, zero_ids = (flags & JDS_ZERO_BASED_IDS) != 0;
+    const int wide_q = (flags & JDS_DQT_16BIT) != 0;
     *out = NULL; *out_len = 0;
     if (restart_interval < 0 || restart_interval > 65535) return -1;
     bitw w; memset(&w, 0, sizeof w);
@@ -299,18 +305,22 @@ int jds_encode(const jds_image* im, int restart_interval, uint8_t** out, size_t*
     { const uint8_t j[14] = { 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 }; for (int i = 0; i < 14; i++) bw_byte(&w, j[i]); }
     /* DQT (zig-zag order in the file) */
     int nq = im->ncomp == 1 ? 1 : 2;
-    bw_u16(&w, 0xFFDB); bw_u16(&w, (unsigned)(2 + 65 * nq));
-    for (int t = 0; t < nq; t++) { bw_byte(&w, (uint8_t)t); for (int i = 0; i < 64; i++) bw_byte(&w, im->qt[t][ZZ[i]]); }
+    bw_u16(&w, 0xFFDB); bw_u16(&w, (unsigned)(2 + (wide_q ? 129 : 65) * nq));
+    for (int t = 0; t < nq; t++) {
+        bw_byte(&w, (uint8_t)(t | (wide_q ? 0x10 : 0)));
+        /* 16-bit form: a non-zero high byte that the reference drops (main.go:60-68) */
+        for (int i = 0; i < 64; i++) { if (wide_q) bw_byte(&w, (uint8_t)(1 + (i & 3))); bw_byte(&w, im->qt[t][ZZ[i]]); }
+    }
     /* SOF0 */
     bw_u16(&w, 0xFFC0); bw_u16(&w, (unsigned)(8 + 3 * im->ncomp)); bw_byte(&w, 8);
     bw_u16(&w, (unsigned)im->height); bw_u16(&w, (unsigned)im->width); bw_byte(&w, (uint8_t)im->ncomp);
     for (int c = 0; c < im->ncomp; c++) {
-        bw_byte(&w, (uint8_t)(c + 1));
+        bw_byte(&w, (uint8_t)(c + (zero_ids ? 0 : 1)));
         bw_byte(&w, c == 0 ? (uint8_t)((im->hs << 4) | im->vs) : 0x11);
         bw_byte(&w, c == 0 ? 0 : 1);
     }
     /* DHT: all tables in one segment */
-    int ntab = im->ncomp == 1 ? 2 : 4;
+    int ntab = (im->ncomp == 1 || shared) ? 2 : 4;
     bw_u16(&w, 0xFFC4);
     bw_u16(&w, (unsigned)(2 + (17 + 12) + (17 + 162) + (ntab == 4 ? (17 + 12) + (17 + 162) : 0)));
     put_dht(&w, 0x00, DC_LUM_BITS, DC_VALS, 12);
@@ -319,7 +329,7 @@ int jds_encode(const jds_image* im, int restart_interval, uint8_t** out, size_t*
     if (restart_interval > 0) { bw_u16(&w, 0xFFDD); bw_u16(&w, 4); bw_u16(&w, (unsigned)restart_interval); }
     /* SOS */
     bw_u16(&w, 0xFFDA); bw_u16(&w, (unsigned)(6 + 2 * im->ncomp)); bw_byte(&w, (uint8_t)im->ncomp);
-    for (int c = 0; c < im->ncomp; c++) { bw_byte(&w, (uint8_t)(c + 1)); bw_byte(&w, c == 0 ? 0x00 : 0x11); }
+    for (int c = 0; c < im->ncomp; c++) { bw_byte(&w, (uint8_t)(c + (zero_ids ? 0 : 1))); bw_byte(&w, (c == 0 || shared) ? 0x00 : 0x11); }
     bw_byte(&w, 0); bw_byte(&w, 63); bw_byte(&w, 0);
     /* ECS */
     int pred[3] = { 0, 0, 0 };
@@ -334,7 +344,7 @@ int jds_encode(const jds_image* im, int restart_interval, uint8_t** out, size_t*
         const int16_t* blk = im->coef + (size_t)m * im->bpm * 64;
         for (int b = 0; b < im->bpm; b++) {
             int comp = b < nlum ? 0 : b - nlum + 1;
-            encode_block(&w, blk + b * 64, &pred[comp], comp ? &dcc : &dcl, comp ? &acc_ : &acl);
+            encode_block(&w, blk + b * 64, &pred[comp], (comp && !shared) ? &dcc : &dcl, (comp && !shared) ? &acc_ : &acl);
         }
     }
     bw_flush_ones(&w);

@@ -116,3 +116,33 @@ def test_synth_encoder_matches_oracle():
         assert np.array_equal(o2.coef, o.coef) and np.array_equal(o2.rgb, o.rgb)
         fr, off, ln = jd.parse(dri)
         assert fr.restart_interval == 3
+
+
+@pytest.mark.parametrize("flags", [jd.SynthImage.ZERO_BASED_IDS, jd.SynthImage.DQT_16BIT, jd.SynthImage.SHARED_TABLES])
+def test_parser_corner_cases(flags):
+    """jd_parse on zero-based component ids (main.go:133-135, 153-157, 961-963), 16-bit DQT entries (low byte kept,
+    main.go:60-68) and one shared table pair: the frame is the plain file's (but for the table ids), and the oracle --
+    which follows the reference's parser -- decodes the odd file to the plain file's coefficients and pixels."""
+    im = jd.SynthImage(100, 75, 2, 1, 3, quality=85, seed=3, detail=2)
+    odd, plain = im.encode(0, flags), im.encode(0)
+    fo, _, _ = jd.parse(odd)
+    fp, _, _ = jd.parse(plain)
+    assert bytes(fo.qt) == bytes(fp.qt) and fo.qt_present == fp.qt_present
+    assert [(c.h, c.v, c.tq) for c in fo.comp] == [(c.h, c.v, c.tq) for c in fp.comp]
+    if flags == jd.SynthImage.SHARED_TABLES:
+        assert [(c.td, c.ta) for c in fo.comp] == [(0, 0)] * 3
+    else:
+        assert [(c.td, c.ta) for c in fo.comp] == [(c.td, c.ta) for c in fp.comp]
+    assert jd._lib().jd_frame_check(ctypes.byref(fo)) == 0
+    oo, op = orclib.OracleImage(odd), orclib.OracleImage(plain)
+    assert np.array_equal(oo.coef, op.coef) and np.array_equal(oo.rgb, op.rgb)
+
+
+def test_parser_empty_sos_is_truncated():
+    """an SOS segment of length 2 as the last bytes of a file: no read past the end"""
+    data = open(os.path.join(REF, "cat1.jpg"), "rb").read()
+    i = data.index(b"\xff\xda")
+    cut = np.frombuffer(data[:i] + b"\xff\xda\x00\x02", np.uint8).copy()
+    with pytest.raises(jd.JpegHipError) as e:
+        jd.parse(cut)
+    assert e.value.code == -10
