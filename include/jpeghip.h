@@ -169,6 +169,25 @@ int jd_batch_host_rgb(jd_batch* b, int image, const uint8_t** rgb, size_t* row_s
 int jd_host_alloc(size_t bytes, void** out);
 void jd_host_free(void* p);
 
+/* ---- allocation-free decode ------------------------------------------------------------------------
+ * No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The same decode as
+ * jd_batch_{create, bind_ecs, bind_rgb, run, wait} for one image, but the whole workspace (descriptors,
+ * tables, unstuffed stream, restart index, sync records, coefficients) lives in a file-scope device array of
+ * the library (12 MiB per device, held until the process ends) whose address jd_init looked up per device:
+ * this call makes no hipMalloc / hipFree / hipHostMalloc and creates no stream or event.
+ *   d_ecs    DEVICE memory, 16-byte aligned: the stuffed entropy-coded segment (as jd_batch_bind_ecs)
+ *   d_rgb    DEVICE memory: height rows of row_stride bytes (as jd_batch_bind_rgb)
+ *   limits   ecs_len <= JD_RESIDENT_MAX_ECS and MCUs x blocks-per-MCU x 64 <= JD_RESIDENT_MAX_COEF
+ *            (1920 x 1080 4:2:0 fits; up to 2.7 MP 4:2:0 or 1.39 MP 4:4:4), else JD_E_TOO_LARGE
+ * Enqueues on hip_stream (NULL = a stream of the library's) and returns when the pixels are in d_rgb.
+ * Calls on one device share that device's array: the library serialises them on the host, so they never
+ * overlap; two PROCESSES are independent (each has its own copy). */
+#define JD_RESIDENT_MAX_ECS (2u << 20)
+#define JD_RESIDENT_MAX_COEF (4u << 20)
+int jd_decode_resident(const jd_frame* frame, const void* d_ecs, size_t ecs_len, void* d_rgb, size_t row_stride,
+                       int device, void* hip_stream);
+
 /* Instrumentation for bench.py / DESIGN.md: runs `iters` decodes of the batch on its own stream and
  * returns, per pipeline stage, the average device time in microseconds measured with hipEvents around
  * that stage's kernels.  names[i] points at static strings.  Returns the number of stages written. */

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "jd_batch_wait", "jd_batch_status", "jd_batch_download", "jd_batch_coefficients", "jd_batch_profile",
     "jd_batch_timing", "jd_batch_stage_times", "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
     "jd_batch_stage_reserve", "jd_batch_stage_ecs", "jd_batch_stage_jpegs", "jd_batch_submit", "jd_batch_host_rgb",
-    "jd_host_alloc", "jd_host_free",
+    "jd_host_alloc", "jd_host_free", "jd_decode_resident",
 ]
 
 
@@ -95,6 +95,7 @@ def _lib():
         L.jd_batch_stage_jpegs.argtypes = [_vp, _ci, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _ci]
         L.jd_batch_submit.argtypes = [_vp, _vp]
         L.jd_batch_host_rgb.argtypes = [_vp, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]
+        L.jd_decode_resident.argtypes = [PF, _vp, _sz, _vp, _sz, _ci, _vp]
         L.jd_host_alloc.argtypes = [_sz, ctypes.POINTER(_vp)]
         L.jd_host_free.argtypes = [_vp]
         L.jd_host_free.restype = None
@@ -182,6 +183,13 @@ def decode_coefficients(data, device=0):
     _check(_lib().jd_decode_coefficients(ctypes.byref(fr), a.ctypes.data + off, ln, 1, None, 0, out.ctypes.data, out.size,
                                          device), "jd_decode_coefficients")
     return out
+
+
+def decode_resident(frame, d_ecs, ecs_len, d_rgb, row_stride, device=0, stream=None):
+    """jd_decode_resident: device-resident in and out, workspace = the library's fixed scratch, no allocation."""
+    _ensure_init()
+    _check(_lib().jd_decode_resident(ctypes.byref(frame), d_ecs, ecs_len, d_rgb, row_stride, device, stream),
+           "jd_decode_resident")
 
 
 def write_bitmap(rgb):

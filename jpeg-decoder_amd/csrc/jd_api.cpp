@@ -32,6 +32,7 @@ void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, const JdIdctConst& K, hipStream_t s);
+int jdk_static_scratch(void** ptr, size_t* bytes);
 }
 
 namespace {
@@ -47,12 +48,17 @@ thread_local int g_last_hip = 0;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- per-device state set up by jd_init ----------------------------------------------------------------
+// `scratch` is the device address of the library's file-scope scratch array on that device (jd_decode_resident works
+// inside it and allocates nothing); `pinned` is the host staging block its descriptors, tables and status words go
+// through.
 struct DevCtx {
     int device = -1;
-    uint8_t* scratch = nullptr; size_t scratch_bytes = 0;   // a fixed device block a batch can be built inside
-    uint8_t* pinned = nullptr; size_t pinned_bytes = 0;     // ... and the pinned host block that goes with it
+    uint8_t* scratch = nullptr; size_t scratch_bytes = 0;
+    uint8_t* pinned = nullptr; size_t pinned_bytes = 0;
     hipStream_t stream = nullptr;
+    std::mutex mu;                            // host-side: one jd_decode_resident at a time per device
 };
+const size_t kStaticPinnedBytes = 1u << 20;
 
 std::mutex g_mu;
 bool g_init = false;
@@ -144,7 +150,7 @@ extern "C" const char* jd_strerror(int code) {
     case JD_E_SYNC: return "internal error: self-synchronising decode did not converge";
     case JD_E_NOT_INIT: return "jd_init has not been called or found no device";
     case JD_E_STATE: return "batch call out of order";
-    case JD_E_TOO_LARGE: return "image too large for a fixed workspace";
+    case JD_E_TOO_LARGE: return "image exceeds the fixed scratch of jd_decode_resident (JD_RESIDENT_MAX_ECS / JD_RESIDENT_MAX_COEF)";
     default: return "unknown error";
     }
 }
@@ -171,8 +177,14 @@ extern "C" int jd_init(const int* device_ids, int n_devices) {
         std::unique_ptr<DevCtx> c(new DevCtx());
         c->device = d;
         hipError_t he = hipSetDevice(d);
+        // each device holds its own copy of the scratch array at its own address: ask with that device current
+        void* p = nullptr; size_t bytes = 0;
+        if (he == hipSuccess && jdk_static_scratch(&p, &bytes) != 0) he = hipErrorInvalidSymbol;
+        if (he == hipSuccess) he = hipHostMalloc((void**)&c->pinned, kStaticPinnedBytes, hipHostMallocDefault);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         g_ctx.push_back(std::move(c));
         if (he != hipSuccess) { g_last_hip = (int)he; rc = JD_E_HIP; break; }
+        g_ctx.back()->scratch = (uint8_t*)p; g_ctx.back()->scratch_bytes = bytes; g_ctx.back()->pinned_bytes = kStaticPinnedBytes;
     }
     g_init = true;
     if (rc != JD_OK) release_ctx_locked();
@@ -953,5 +965,33 @@ extern "C" int jd_decode_coefficients(const jd_frame* frame, const uint8_t* ecs,
     if (rc) return rc;
     rc = jd_batch_coefficients(b, 0, coef_out, coef_cap);
     jd_batch_destroy(b);
+    return rc;
+}
+
+// ---- allocation-free entry point ---------------------------------------------------------------------------
+// jd_batch_{create, bind_ecs, bind_rgb, run, wait} for ONE image, with the workspace taken from the library's file-scope
+// device array instead of hipMalloc: no hipMalloc / hipFree / hipHostMalloc / stream or event creation happens here
+// (the array's address, the pinned block and the stream were set up per device by jd_init).  Calls on one device share
+// that device's array: they are serialised on the host by a mutex, and each call clears what must start at zero (stream
+// pads, status and sync flags, K0 tickets and look-back words) on the stream before its kernels.
+extern "C" int jd_decode_resident(const jd_frame* frame, const void* d_ecs, size_t ecs_len, void* d_rgb, size_t row_stride,
+                                  int device, void* hip_stream) {
+    if (!frame || !d_ecs || !d_rgb || ecs_len == 0) return JD_E_ARG;
+    DevCtx* ctx = find_ctx(device);
+    if (!ctx) return jd_device_count() ? JD_E_ARG : JD_E_NOT_INIT;
+    Geometry g; int rc = frame_geometry(frame, &g);
+    if (rc) return rc;
+    if (ecs_len > JD_RESIDENT_MAX_ECS || (uint64_t)g.mcux * g.mcuy * g.bpm * 64 > JD_RESIDENT_MAX_COEF) return JD_E_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    jd_batch* b = nullptr;
+    rc = batch_build(device, 1, frame, &ecs_len, 0, ctx, s, &b);
+    if (rc) return rc;
+    rc = jd_batch_bind_ecs(b, 0, d_ecs, ecs_len);
+    if (!rc) rc = jd_batch_bind_rgb(b, 0, d_rgb, row_stride);
+    if (!rc) rc = run_on(b, s);
+    if (!rc) rc = wait_on(b);
+    else (void)hipStreamSynchronize(s);                      // nothing of this call may still read the shared blocks
+    batch_release(b);
     return rc;
 }

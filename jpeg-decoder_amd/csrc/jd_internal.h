@@ -68,6 +68,10 @@
 // IDCT + colour kernel: MCUs per workgroup (one wave per block-in-MCU, one lane per MCU)
 #define JD_TILE_MCUS 64
 
+// jd_decode_resident: bytes of the file-scope device array it works in (coefficients JD_RESIDENT_MAX_COEF x 2 B,
+// unstuffed stream JD_RESIDENT_MAX_ECS, and up to 2 MiB of descriptors, tables, restart index and sync records)
+#define JD_RESIDENT_SCRATCH_BYTES (12u << 20)
+
 // per-image status bits written by the kernels
 enum {
     JD_ST_MARKER = 1u << 0,      // non-RST marker inside the ECS

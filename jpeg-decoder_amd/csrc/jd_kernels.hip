@@ -1247,6 +1247,26 @@ __global__ __launch_bounds__(64, 2) void k2_mcu_lanes(JdKernelArgs a, JdIdctCons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fixed workspace of jd_decode_resident (include/jpeghip.h): callers that cannot allocate get the whole decode
+// workspace -- descriptors, tables, unstuffed stream, restart index, sync records, coefficients -- out of this array.
+// Each device the library runs on holds its own copy until the process ends.  The name is a host-side stand-in, not a
+// device address: host code asks for the address once per device (jdk_static_scratch, from jd_init with that device
+// current) and hands THAT pointer to memsets, copies and kernels.  (No __attribute__((used)) here: with it hipcc keeps the
+// device symbol LOCAL instead of externalising it for the host's use, and hipGetSymbolAddress aborts the process.)
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) uint8_t scratch[JD_RESIDENT_SCRATCH_BYTES];
+
+extern "C" int jdk_static_scratch(void** ptr, size_t* bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) return e != hipSuccess ? (int)e : -1;
+    size_t n = 0;
+    if (hipGetSymbolSize(&n, HIP_SYMBOL(scratch)) != hipSuccess || n != JD_RESIDENT_SCRATCH_BYTES) return -1;
+    *ptr = p; *bytes = n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 extern "C" {
