@@ -118,7 +118,8 @@ typedef struct jd_batch jd_batch;
 
 enum {
     JD_BATCH_KEEP_COEF = 1u,  /* keep coefficients readable after run (jd_batch_coefficients)           */
-    JD_BATCH_PINNED_IO = 2u   /* library-owned pinned staging + copy streams: jd_batch_stage_* / jd_batch_submit */
+    JD_BATCH_PINNED_IO = 2u,  /* library-owned pinned staging + copy streams: jd_batch_stage_* / jd_batch_submit */
+    JD_BATCH_EXTERNAL_IO = 4u /* every image will be bound (jd_batch_bind_ecs / _rgb): no ECS / RGB buffers of its own */
 };
 
 int jd_batch_create(int device, int n_images, const jd_frame* frames, const size_t* ecs_cap,

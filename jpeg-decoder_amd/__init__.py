@@ -207,14 +207,14 @@ def write_bitmap(rgb):
 class Batch:
     """jd_batch: n images decoded by one fixed sequence of batched kernels on one device."""
 
-    def __init__(self, frames, ecs_caps, device=0, keep_coef=False, pinned_io=False):
+    def __init__(self, frames, ecs_caps, device=0, keep_coef=False, pinned_io=False, external_io=False):
         _ensure_init()
         n = len(frames)
         self.n, self.device = n, device
         self.frames = (Frame * n)(*frames)
         caps = (_sz * n)(*[int(c) for c in ecs_caps])
         h = _vp()
-        flags = (1 if keep_coef else 0) | (2 if pinned_io else 0)
+        flags = (1 if keep_coef else 0) | (2 if pinned_io else 0) | (4 if external_io else 0)
         _check(_lib().jd_batch_create(device, n, self.frames, caps, flags, ctypes.byref(h)), "jd_batch_create")
         self._h = h
 
@@ -325,6 +325,16 @@ def shard_images(n_images, world, rank):
     if world < 1 or not 0 <= rank < world:
         raise ValueError("bad rank %d / world %d" % (rank, world))
     return list(range(rank, n_images, world))
+
+
+def plan_job(total, world, rank, per_batch, distinct):
+    """A rank's share of a job of `total` images (BASELINE config 5: "batch of 10k 1080p sharded across 1/2/4/8"), cut
+    into jd_batch-sized groups: -> list of batches, each a list of (global image index, seed).  Image g of the job is the
+    synthetic image with seed g % distinct; shard_images deals the indices; nothing is exchanged between ranks."""
+    if per_batch < 1 or distinct < 1:
+        raise ValueError("per_batch and distinct must be positive")
+    mine = shard_images(total, world, rank)
+    return [[(g, g % distinct) for g in mine[b0:b0 + per_batch]] for b0 in range(0, len(mine), per_batch)]
 
 
 def max_over_ranks(seconds, dist=None, device=None):

@@ -521,7 +521,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     int rc = JD_OK;
     auto A = [&](void* pp, size_t bytes) { if (rc == JD_OK) rc = b->arena.take((void**)pp, bytes); };
     A(&b->d_desc, b->desc_bytes);
-    if (!dev) {                                                   // a fixed-block batch reads and writes the caller's buffers only
+    if (!dev && !(flags & JD_BATCH_EXTERNAL_IO)) {                // (a fixed-block batch reads and writes the caller's buffers only)
         A(&b->d_ecs_own, ecs_own);
         A(&b->d_rgb_own, rgb_own);
     }
@@ -577,7 +577,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     }
     // ---- pinned I/O staging + copy streams -------------------------------------------------------------
     if (rc == JD_OK && (flags & JD_BATCH_PINNED_IO)) {
-        if (dev) rc = JD_E_ARG;
+        if (dev || (flags & JD_BATCH_EXTERNAL_IO)) rc = JD_E_ARG;
         else {
             hipError_t he = hipHostMalloc((void**)&b->h_ecs, std::max<size_t>(ecs_own, 256), hipHostMallocDefault);
             if (he == hipSuccess) he = hipHostMalloc((void**)&b->h_rgb, std::max<size_t>(rgb_own, 256), hipHostMallocDefault);
