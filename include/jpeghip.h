@@ -202,6 +202,33 @@ int jd_batch_stage_times(jd_batch* b, float* stage_us, const char** names, int c
 size_t jd_batch_workspace_bytes(const jd_batch* b);
 int jd_batch_unstuffed_len(jd_batch* b, int image, size_t* len);
 
+/* ---- progressive (SOF2) files: SURVEY row N4 ----------------------------------------------------
+ * Replaces the SOF2 branch of decodeBandCoeffecients (main.go:241-428) and the scan chaining of
+ * decodeStartOfScan (main.go:1035-1062).  The Go host keeps parsing SOS / DHT / DRI between the scans and hands
+ * over one jd_scan per SOS: the scan header (main.go:954-987), the tables in force at that point (a DHT between
+ * two scans may redefine an id, main.go:1049-1052) and where the scan's entropy-coded bytes lie in the file.
+ * Coefficients accumulate over the scans exactly as Header.blocks does; dequantisation, IDCT, chroma spread and
+ * colour conversion then run as for a baseline frame (main.go:1054-1057).  As in the reference, restart markers
+ * inside a progressive scan are dropped and not acted upon. */
+typedef struct jd_scan {
+    uint8_t progressive;      /* 1: frame type SOF2 (the same in every scan of a file); 0: the single scan of an SOF0 file */
+    uint8_t ncomp;            /* Header.componentsInScan (main.go:956)                                            */
+    uint8_t comp[3];          /* frame index of each component of the scan, in the scan header's order               */
+    uint8_t td[3], ta[3];     /* their DC / AC table ids (main.go:966-967)                                          */
+    uint8_t ss, se, ah, al;   /* startOfSelection, endOfSelection, successiveApproximationHigh / Low (main.go:980-987) */
+    uint64_t ecs_off, ecs_len; /* the scan's stuffed entropy-coded bytes: offset in the file and length               */
+    jd_huff huff[2][4];       /* Header.huffmanTables as they stand when this scan starts                            */
+} jd_scan;
+/* Parser twin for SOF0 and SOF2 files (decodeJPEG ... decodeStartOfScan's header work, main.go:1076-1154, 942-1021,
+ * 1035-1052): fills the frame and up to `cap` scans; *n_scans = scans in the file (JD_E_ARG if cap is too small). */
+int jd_parse_scans(const uint8_t* file, size_t file_len, jd_frame* frame, jd_scan* scans, int cap, int* n_scans);
+/* Decode a file given as frame + scans (host memory in, host memory out; synchronous). */
+int jd_decode_scans(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file, size_t file_len,
+                    uint8_t* rgb_out, size_t row_stride, int device);
+/* Parity hook: the accumulated coefficients after the last scan, layout as jd_decode_coefficients. */
+int jd_decode_scans_coefficients(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file,
+                                 size_t file_len, int16_t* coef_out, size_t coef_cap, int device);
+
 /* ---- host-side twin of the Go marker parser (test harness / CLI; Go keeps its own in production) --
  * Parses a baseline JPEG held in memory the way decodeJPEG and friends do (main.go:1076-1154, 42-180,
  * 818-888, 942-987) and returns the frame plus the extent of the stuffed entropy-coded segment

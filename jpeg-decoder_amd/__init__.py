@@ -35,6 +35,13 @@ class Frame(ctypes.Structure):
                 ("huff", (Huff * 4) * 2)]
 
 
+class Scan(ctypes.Structure):
+    """jd_scan: one SOS of a progressive file -- scan header, tables in force, extent of its entropy-coded bytes."""
+    _fields_ = [("progressive", _u8), ("ncomp", _u8), ("comp", _u8 * 3), ("td", _u8 * 3), ("ta", _u8 * 3),
+                ("ss", _u8), ("se", _u8), ("ah", _u8), ("al", _u8), ("ecs_off", ctypes.c_uint64), ("ecs_len", ctypes.c_uint64),
+                ("huff", (Huff * 4) * 2)]
+
+
 # every symbol include/jpeghip.h declares (tests/test_abi.py checks the library exports exactly these)
 ABI_SYMBOLS = [
     "jd_strerror", "jd_last_hip_error", "jd_init", "jd_shutdown", "jd_device_count", "jd_frame_check",
@@ -43,7 +50,7 @@ ABI_SYMBOLS = [
     "jd_batch_wait", "jd_batch_status", "jd_batch_download", "jd_batch_coefficients", "jd_batch_profile",
     "jd_batch_timing", "jd_batch_stage_times", "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
     "jd_batch_stage_reserve", "jd_batch_stage_ecs", "jd_batch_stage_jpegs", "jd_batch_submit", "jd_batch_host_rgb",
-    "jd_host_alloc", "jd_host_free", "jd_decode_resident",
+    "jd_host_alloc", "jd_host_free", "jd_decode_resident", "jd_parse_scans", "jd_decode_scans", "jd_decode_scans_coefficients",
 ]
 
 
@@ -96,6 +103,10 @@ def _lib():
         L.jd_batch_submit.argtypes = [_vp, _vp]
         L.jd_batch_host_rgb.argtypes = [_vp, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]
         L.jd_decode_resident.argtypes = [PF, _vp, _sz, _vp, _sz, _ci, _vp]
+        PS = ctypes.POINTER(Scan)
+        L.jd_parse_scans.argtypes = [_vp, _sz, PF, PS, _ci, ctypes.POINTER(_ci)]
+        L.jd_decode_scans.argtypes = [PF, PS, _ci, _vp, _sz, _vp, _sz, _ci]
+        L.jd_decode_scans_coefficients.argtypes = [PF, PS, _ci, _vp, _sz, _vp, _sz, _ci]
         L.jd_host_alloc.argtypes = [_sz, ctypes.POINTER(_vp)]
         L.jd_host_free.argtypes = [_vp]
         L.jd_host_free.restype = None
@@ -144,6 +155,14 @@ def parse(data):
     return fr, off.value, ln.value
 
 
+def parse_scans(data, cap=64):
+    """jd_parse_scans: frame + one Scan per SOS of an SOF0 or SOF2 file (main.go:942-1021, 1035-1052).  -> (Frame, [Scan])"""
+    a = _as_u8(data)
+    fr, scans, n = Frame(), (Scan * cap)(), _ci()
+    _check(_lib().jd_parse_scans(a.ctypes.data, a.size, ctypes.byref(fr), scans, cap, ctypes.byref(n)), "jd_parse_scans")
+    return fr, scans, n.value
+
+
 def geometry(frame):
     mx, my, bpm = _u32(), _u32(), _u32()
     _check(_lib().jd_frame_geometry(ctypes.byref(frame), ctypes.byref(mx), ctypes.byref(my), ctypes.byref(bpm)),
@@ -151,11 +170,34 @@ def geometry(frame):
     return mx.value, my.value, bpm.value
 
 
-def decode_jpeg(data, device=0):
-    """Parse + jd_decode: the whole of decodeJPEG up to (not including) writeBitMap.  -> H x W x 3 uint8 RGB."""
+def decode_progressive(data, device=0, coefficients=False):
+    """jd_parse_scans + jd_decode_scans: an SOF2 (or SOF0) file scan by scan.  -> RGB, or the accumulated coefficients."""
     _ensure_init()
     a = _as_u8(data)
-    fr, off, ln = parse(a)
+    fr, scans, n = parse_scans(a)
+    if coefficients:
+        mx, my, bpm = geometry(fr)
+        out = np.empty((mx * my, bpm, 64), np.int16)
+        _check(_lib().jd_decode_scans_coefficients(ctypes.byref(fr), scans, n, a.ctypes.data, a.size, out.ctypes.data, out.size,
+                                                   device), "jd_decode_scans_coefficients")
+        return out
+    out = np.empty((fr.height, fr.width, 3), np.uint8)
+    _check(_lib().jd_decode_scans(ctypes.byref(fr), scans, n, a.ctypes.data, a.size, out.ctypes.data, fr.width * 3, device),
+           "jd_decode_scans")
+    return out
+
+
+def decode_jpeg(data, device=0):
+    """Parse + jd_decode: the whole of decodeJPEG up to (not including) writeBitMap.  -> H x W x 3 uint8 RGB.
+    Progressive files (which jd_parse leaves to jd_parse_scans) go through decode_progressive."""
+    _ensure_init()
+    a = _as_u8(data)
+    try:
+        fr, off, ln = parse(a)
+    except JpegHipError as e:
+        if e.code != -2:
+            raise
+        return decode_progressive(a, device)
     out = np.empty((fr.height, fr.width, 3), np.uint8)
     _check(_lib().jd_decode(ctypes.byref(fr), a.ctypes.data + off, ln, 1, None, 0, out.ctypes.data, fr.width * 3, device),
            "jd_decode")

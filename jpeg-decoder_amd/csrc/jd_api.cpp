@@ -32,6 +32,8 @@ void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, const JdIdctConst& K, hipStream_t s);
+void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
+                      const uint32_t* d_plut, hipStream_t s);
 int jdk_static_scratch(void** ptr, size_t* bytes);
 }
 
@@ -994,4 +996,143 @@ extern "C" int jd_decode_resident(const jd_frame* frame, const void* d_ecs, size
     else (void)hipStreamSynchronize(s);                      // nothing of this call may still read the shared blocks
     batch_release(b);
     return rc;
+}
+
+// ---- progressive files ---------------------------------------------------------------------
+// Host side of jd_decode_scans: unstuff every scan the way main.go:993-1021 does (FF00 -> FF, RSTn dropped -- the
+// reference never acts on restart markers, least of all in progressive scans -- FF fill bytes skipped), pack the symbol
+// tables each scan names, order the scans in dependency levels, run kp_scan level by level, then K2 as for any frame.
+namespace {
+
+struct DevBuf {                       // hipMalloc'ed scratch of one call
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 256))); return JD_OK; }
+};
+
+int decode_scans_impl(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file, size_t file_len,
+                      uint8_t* rgb_out, size_t row_stride, int16_t* coef_out, size_t coef_cap, int device) {
+    if (!frame || !scans || n_scans <= 0 || !file) return JD_E_ARG;
+    Geometry g; int rc = frame_geometry(frame, &g);
+    if (rc) return rc;
+    if (!scans[0].progressive) {                               // an SOF0 file: the baseline path
+        if (n_scans != 1 || scans[0].ecs_off + scans[0].ecs_len > file_len) return JD_E_ARG;
+        return coef_out ? jd_decode_coefficients(frame, file + scans[0].ecs_off, scans[0].ecs_len, 1, nullptr, 0, coef_out, coef_cap, device)
+                        : jd_decode(frame, file + scans[0].ecs_off, scans[0].ecs_len, 1, nullptr, 0, rgb_out, row_stride, device);
+    }
+    for (int c = 0; c < frame->ncomp; c++)
+        if (frame->comp[c].tq > 3 || !(frame->qt_present & (1u << frame->comp[c].tq))) return JD_E_TABLE;
+    // ---- per scan: unstuffed bytes, tables, descriptor ----
+    std::vector<uint8_t> stream;
+    std::vector<uint32_t> lut(1, 0);                           // entry 0 stays unused (offset 0 = "no table" is never read)
+    std::vector<JdPScan> ps(n_scans);
+    std::vector<int> level(n_scans, 0);
+    int n_levels = 0;
+    for (int k = 0; k < n_scans; k++) {
+        const jd_scan& sc = scans[k];
+        if (!sc.progressive || sc.ncomp < 1 || sc.ncomp > frame->ncomp || sc.se > 63 || sc.ss > sc.se || sc.al > 13) return JD_E_ARG;
+        if (sc.ecs_off > file_len || sc.ecs_len > file_len - sc.ecs_off) return JD_E_ARG;
+        if (sc.ss == 0 && sc.se != 0) return JD_E_UNSUPPORTED; // T.81 G.1.1.1.1: a DC scan holds DC only (the reference would mix the cases up)
+        if (sc.ss != 0 && sc.ncomp != 1) return JD_E_UNSUPPORTED;   // AC scans are never interleaved (the reference's skips counter assumes it)
+        JdPScan& d = ps[k];
+        memset(&d, 0, sizeof d);
+        d.img = 0; d.ss = sc.ss; d.se = sc.se; d.ah = sc.ah; d.al = sc.al; d.ncomp = sc.ncomp;
+        // the reference walks the FRAME's components and decodes those the scan uses (main.go:771-775): ascending order
+        int order[3] = { 0, 1, 2 };
+        std::sort(order, order + sc.ncomp, [&](int p, int q) { return sc.comp[p] < sc.comp[q]; });
+        for (int j = 0; j < sc.ncomp; j++) {
+            const int src = order[j];
+            if (sc.comp[src] >= frame->ncomp || (j && sc.comp[src] == sc.comp[order[j - 1]])) return JD_E_ARG;
+            d.comp[j] = sc.comp[src]; d.dc_lut[j] = d.ac_lut[j] = 0xFFFFFFFFu;
+            const bool need_dc = sc.ss == 0 && sc.ah == 0, need_ac = sc.ss != 0;
+            if (need_dc) {
+                if (sc.td[src] > 3 || !sc.huff[0][sc.td[src]].present) return JD_E_TABLE;
+                const jd_huff& h = sc.huff[0][sc.td[src]];
+                d.dc_lut[j] = (uint32_t)lut.size();
+                if (jd_pack_lut_sym(h.bits, h.vals, h.nvals, lut)) return JD_E_TABLE;
+            }
+            if (need_ac) {
+                if (sc.ta[src] > 3 || !sc.huff[1][sc.ta[src]].present) return JD_E_TABLE;
+                const jd_huff& h = sc.huff[1][sc.ta[src]];
+                d.ac_lut[j] = (uint32_t)lut.size();
+                if (jd_pack_lut_sym(h.bits, h.vals, h.nvals, lut)) return JD_E_TABLE;
+            }
+        }
+        // unstuff (main.go:993-1021)
+        while (stream.size() % 16) stream.push_back(0);
+        d.stream_off = (uint32_t)stream.size();
+        const uint8_t* e = file + sc.ecs_off;
+        for (size_t i = 0; i < sc.ecs_len; i++) {
+            if (e[i] != 0xFF) { stream.push_back(e[i]); continue; }
+            if (i + 1 >= sc.ecs_len) break;                    // (the parser ends the extent in front of the closing marker)
+            const uint8_t nx = e[i + 1];
+            if (nx == 0x00) { stream.push_back(0xFF); i++; }
+            else if (nx >= 0xD0 && nx <= 0xD7) i++;            // RSTn: dropped
+            else if (nx == 0xFF) continue;                     // fill byte
+            else return JD_E_MARKER;
+        }
+        d.stream_len = (uint32_t)(stream.size() - d.stream_off);
+        for (int z = 0; z < 16; z++) stream.push_back(0);
+        // dependency level: after every earlier scan that touches one of its components in an overlapping band
+        for (int i = 0; i < k; i++) {
+            bool share = false;
+            for (int p = 0; p < sc.ncomp; p++) for (int q = 0; q < scans[i].ncomp; q++) share |= sc.comp[p] == scans[i].comp[q];
+            if (share && !(sc.se < scans[i].ss || scans[i].se < sc.ss)) level[k] = std::max(level[k], level[i] + 1);
+        }
+        n_levels = std::max(n_levels, level[k] + 1);
+    }
+    if (stream.size() >= (size_t)1 << 31) return JD_E_ARG;
+    // ---- device: a one-image batch supplies geometry, quantisation tables, coefficient buffer and K2 ----
+    jd_frame fr = *frame;                                      // the batch needs SOME valid table pair per component; K0/K1 never run
+    memset(fr.huff, 0, sizeof fr.huff);
+    fr.huff[0][0].bits[0] = 1; fr.huff[0][0].nvals = 1; fr.huff[0][0].present = 1;
+    fr.huff[1][0] = fr.huff[0][0];
+    for (int c = 0; c < fr.ncomp; c++) fr.comp[c].td = fr.comp[c].ta = 0;
+    fr.restart_interval = 0;
+    jd_batch* b = nullptr;
+    size_t cap1 = 16;
+    rc = jd_batch_create(device, 1, &fr, &cap1, JD_BATCH_KEEP_COEF, &b);
+    if (rc) return rc;
+    struct Guard { jd_batch* b; ~Guard() { batch_release(b); } } guard{ b };
+    DevBuf d_stream, d_lut, d_scans, d_list;
+    std::vector<uint32_t> list;
+    std::vector<int> level_start(n_levels + 1, 0);
+    for (int l = 0; l < n_levels; l++) {
+        for (int k = 0; k < n_scans; k++) if (level[k] == l) list.push_back((uint32_t)k);
+        level_start[l + 1] = (int)list.size();
+    }
+    if ((rc = d_stream.alloc(stream.size())) || (rc = d_lut.alloc(lut.size() * 4)) || (rc = d_scans.alloc(ps.size() * sizeof(JdPScan))) ||
+        (rc = d_list.alloc(list.size() * 4))) return rc;
+    hipStream_t s = b->stream;
+    HIPCHK(hipMemcpyAsync(d_stream.p, stream.data(), stream.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_lut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_scans.p, ps.data(), ps.size() * sizeof(JdPScan), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(b->d_coef, 0, b->coef_elems * sizeof(int16_t), s));   // scans only write what they code
+    rc = refresh(b, s); if (rc) return rc;
+    rc = enqueue_stage(b, ST_CLEAR, s); if (rc) return rc;
+    const JdKernelArgs a = kernel_args(b);
+    for (int l = 0; l < n_levels; l++)
+        jdk_launch_pscan(a, (const JdPScan*)d_scans.p, (const uint32_t*)d_list.p + level_start[l], level_start[l + 1] - level_start[l],
+                         (const uint8_t*)d_stream.p, (const uint32_t*)d_lut.p, s);
+    HIPCHK(hipGetLastError());
+    rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
+    b->ran = true; b->last_stream = s;
+    rc = wait_on(b);                                           // synchronises: the pageable sources above are free again
+    if (rc) return rc;
+    return coef_out ? jd_batch_coefficients(b, 0, coef_out, coef_cap) : jd_batch_download(b, 0, rgb_out, row_stride);
+}
+
+}  // namespace
+
+extern "C" int jd_decode_scans(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file, size_t file_len,
+                               uint8_t* rgb_out, size_t row_stride, int device) {
+    if (!rgb_out) return JD_E_ARG;
+    return decode_scans_impl(frame, scans, n_scans, file, file_len, rgb_out, row_stride, nullptr, 0, device);
+}
+
+extern "C" int jd_decode_scans_coefficients(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file,
+                                            size_t file_len, int16_t* coef_out, size_t coef_cap, int device) {
+    if (!coef_out) return JD_E_ARG;
+    return decode_scans_impl(frame, scans, n_scans, file, file_len, nullptr, 0, coef_out, coef_cap, device);
 }

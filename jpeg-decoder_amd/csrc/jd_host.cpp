@@ -37,22 +37,32 @@ struct Reader {
 
 }  // namespace
 
-extern "C" int jd_parse(const uint8_t* file, size_t file_len, jd_frame* fr, size_t* ecs_off, size_t* ecs_len) {
+// One parser for both frame types.  scans == nullptr: the baseline form (jd_parse): SOF0 only, exactly one scan, its
+// extent returned through ecs_off / ecs_len.
+static int parse_impl(const uint8_t* file, size_t file_len, jd_frame* fr, jd_scan* scans, int cap, int* n_scans,
+                      size_t* ecs_off, size_t* ecs_len) {
     static const ZZ zz;
-    if (!file || !fr || !ecs_off || !ecs_len) return JD_E_ARG;
     memset(fr, 0, sizeof *fr);
     Reader r{ file, file_len, 0 };
     if (!r.ok(2) || file[0] != 0xFF || file[1] != 0xD8) return JD_E_MARKER;       // SOI (main.go:1095)
     r.i = 2;
     int comp_id[3] = { 0, 0, 0 };
-    bool have_sof = false, zero_based = false;
+    bool have_sof = false, zero_based = false, progressive = false;
+    int ns_found = 0;
     for (;;) {
         if (!r.ok(2)) return JD_E_TRUNCATED;
         if (r.u8() != 0xFF) return JD_E_MARKER;                                   // main.go:1103-1106
         int m = r.u8();
         while (m == 0xFF) { if (!r.ok(1)) return JD_E_TRUNCATED; m = r.u8(); }     // fill bytes (main.go:1108-1110)
         if (m == 0x01) continue;                                                  // TEM: no payload
-        if (m == 0xD9 || m == 0xD8) return JD_E_MARKER;                           // EOI before SOS / embedded SOI
+        if (m == 0xD9) {                                                          // EOI
+            if (ns_found == 0) return JD_E_MARKER;                                // EOI before SOS (main.go:1131-1134)
+            if (n_scans) *n_scans = ns_found;
+            return JD_OK;
+        }
+        if (m == 0xD8) return JD_E_MARKER;                                        // embedded SOI
+        if (ns_found && !(m == 0xDD || m == 0xC4 || m == 0xDA)) return JD_E_MARKER;   // after a scan the reference only
+                                                                                  // knows DRI / DHT / SOS / EOI (main.go:1041-1053)
         if (!r.ok(2)) return JD_E_TRUNCATED;
         const int seg = r.u16();
         if (seg < 2 || !r.ok((size_t)seg - 2)) return JD_E_TRUNCATED;
@@ -69,7 +79,8 @@ extern "C" int jd_parse(const uint8_t* file, size_t file_len, jd_frame* fr, size
                 }
                 fr->qt_present |= (uint8_t)(1u << id);
             }
-        } else if (m == 0xC0) {                                                   // SOF0
+        } else if (m == 0xC0 || (m == 0xC2 && scans)) {                           // SOF0 / SOF2
+            if (have_sof) return JD_E_MARKER;
             if (seg < 8) return JD_E_TRUNCATED;
             if (r.u8() != 8) return JD_E_UNSUPPORTED;                             // precision (main.go:97-100)
             fr->height = (uint16_t)r.u16();
@@ -87,9 +98,9 @@ extern "C" int jd_parse(const uint8_t* file, size_t file_len, jd_frame* fr, size
                 for (int b = 0; b < a; b++) if (comp_id[b] == comp_id[a]) return JD_E_UNSUPPORTED;
             }
             if (zero_based) for (int a = 0; a < nc; a++) comp_id[a] += 1;         // main.go:153-157
-            have_sof = true;
+            have_sof = true; progressive = m == 0xC2;
         } else if (m >= 0xC1 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            return JD_E_UNSUPPORTED;                                              // progressive etc.: outside the path
+            return JD_E_UNSUPPORTED;                                              // progressive through jd_parse, lossless, ...
         } else if (m == 0xCC) {
             return JD_E_UNSUPPORTED;                                              // arithmetic coding
         } else if (m == 0xDD) {                                                   // DRI
@@ -112,36 +123,67 @@ extern "C" int jd_parse(const uint8_t* file, size_t file_len, jd_frame* fr, size
             if (!have_sof) return JD_E_MARKER;
             if (r.i >= end) return JD_E_TRUNCATED;                                // empty SOS payload: nothing to read
             const int ns = r.u8();
-            if (r.i + (size_t)ns * 2 + 3 > end) return JD_E_TRUNCATED;
+            if (ns < 1 || ns > 3 || r.i + (size_t)ns * 2 + 3 > end) return JD_E_TRUNCATED;
+            jd_scan local; jd_scan* sc = &local;
+            if (scans) { if (ns_found >= cap) return JD_E_ARG; sc = &scans[ns_found]; }
+            memset(sc, 0, sizeof *sc);
+            sc->progressive = progressive ? 1 : 0; sc->ncomp = 0;
             int used = 0;
             for (int a = 0; a < ns; a++) {
                 int id = r.u8();
                 if (zero_based) id += 1;                                          // main.go:961-963
                 const int t = r.u8();
                 for (int c = 0; c < fr->ncomp; c++)
-                    if (comp_id[c] == id) { fr->comp[c].td = (uint8_t)(t >> 4); fr->comp[c].ta = (uint8_t)(t & 15); used |= 1 << c; }
+                    if (comp_id[c] == id && !(used & (1 << c))) {
+                        fr->comp[c].td = (uint8_t)(t >> 4); fr->comp[c].ta = (uint8_t)(t & 15); used |= 1 << c;
+                        sc->comp[sc->ncomp] = (uint8_t)c; sc->td[sc->ncomp] = (uint8_t)(t >> 4); sc->ta[sc->ncomp] = (uint8_t)(t & 15);
+                        sc->ncomp++;
+                    }
             }
-            if (used != (1 << fr->ncomp) - 1) return JD_E_UNSUPPORTED;            // single interleaved scan only
+            if (!progressive && used != (1 << fr->ncomp) - 1) return JD_E_UNSUPPORTED;   // baseline: single interleaved scan only
+            if (sc->ncomp != ns) return JD_E_UNSUPPORTED;                         // a scan component that the frame does not have
+            sc->ss = (uint8_t)r.u8(); sc->se = (uint8_t)r.u8();
+            { const int aa = r.u8(); sc->ah = (uint8_t)(aa >> 4); sc->al = (uint8_t)(aa & 15); }
+            if (progressive && (sc->se > 63 || sc->ss > sc->se || sc->al > 13)) return JD_E_UNSUPPORTED;
+            memcpy(sc->huff, fr->huff, sizeof sc->huff);
             r.i = end;
             // extent of the entropy-coded segment: up to the first FF that is followed by neither 00, FF nor
-            // RSTn (the reference stops at EOI and treats anything else as fatal, main.go:1001-1016)
+            // RSTn (main.go:993-1021: EOI ends it; in a progressive file so do DRI, DHT and SOS; anything else is fatal)
             const size_t start = r.i;
             size_t i = start;
+            uint8_t nx = 0;
             for (;;) {
                 const uint8_t* q = (const uint8_t*)memchr(file + i, 0xFF, file_len - i);
                 if (!q || (size_t)(q - file) + 1 >= file_len) return JD_E_TRUNCATED;   // EOF before EOI (main.go:22-25)
                 i = (size_t)(q - file);
-                const uint8_t nx = file[i + 1];
+                nx = file[i + 1];
                 if (nx == 0x00 || (nx >= 0xD0 && nx <= 0xD7)) { i += 2; continue; }
                 if (nx == 0xFF) { i += 1; continue; }
-                if (nx != 0xD9) return JD_E_MARKER;
                 break;
             }
-            *ecs_off = start; *ecs_len = i - start;
-            return JD_OK;
+            if (!(nx == 0xD9 || (progressive && (nx == 0xDD || nx == 0xC4 || nx == 0xDA)))) return JD_E_MARKER;
+            sc->ecs_off = start; sc->ecs_len = i - start;
+            ns_found++;
+            if (!scans) {                                                         // baseline form: done at the first scan
+                *ecs_off = start; *ecs_len = i - start;
+                return JD_OK;
+            }
+            r.i = i;                                                              // at the FF of the marker that ended the scan
+            continue;
         }
         r.i = end;                                                                // APPn, COM, JPGn, DNL, DHP, EXP: skipped
     }
+}
+
+extern "C" int jd_parse(const uint8_t* file, size_t file_len, jd_frame* fr, size_t* ecs_off, size_t* ecs_len) {
+    if (!file || !fr || !ecs_off || !ecs_len) return JD_E_ARG;
+    return parse_impl(file, file_len, fr, nullptr, 0, nullptr, ecs_off, ecs_len);
+}
+
+extern "C" int jd_parse_scans(const uint8_t* file, size_t file_len, jd_frame* fr, jd_scan* scans, int cap, int* n_scans) {
+    if (!file || !fr || !scans || cap <= 0 || !n_scans) return JD_E_ARG;
+    *n_scans = 0;
+    return parse_impl(file, file_len, fr, scans, cap, n_scans, nullptr, nullptr);
 }
 
 extern "C" long jd_bmp_encode(const uint8_t* rgb, size_t row_stride, int width, int height, uint8_t* out, size_t cap) {

@@ -7,6 +7,7 @@
 //                                          1156-1169, 1252-1316)
 //       k1_dc_scan                         DC-prediction prefix scan as its own pass (images whose components all
 //                                          share one table pair: the block-in-MCU phase cannot self-synchronise)
+//   P   kp_scan                            progressive (SOF2) scans, one lane per scan (main.go:241-428)
 //   K2  k2_mcu_lanes                       dequantise + de-zigzag + fp64 truncating IDCT + chroma spread +
 //                                          float32 YCbCr->RGB (main.go:638-666, 454-606, 710-747, 669-707;
 //                                          zmap/map.go:3-68)
@@ -991,6 +992,155 @@ __global__ __launch_bounds__(1024) void k1_dc_scan(JdKernelArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Progressive (SOF2) scans, SURVEY row N4: decodeBandCoeffecients' SOF2 branch (main.go:241-428) under decodeHuffmanData's
+// block walk (main.go:749-816).  A progressive scan has no restart structure the reference acts on and every scan refines
+// what earlier scans of the same band left, so the unit of parallel work is the SCAN: one lane per scan, scans that do not
+// depend on each other (different components or disjoint bands) in one launch, dependent ones in later launches (the
+// host orders them in levels).  Coefficients accumulate in the same int16 buffer, same layout, as the baseline writer's;
+// K2 then runs unchanged.
+// ------------------------------------------------------------------------------------------------
+struct PBits {                 // MSB-first reader over an unstuffed scan (BitReader, main.go:1252-1295)
+    const uint32_t* p;         // stream, read as aligned big-endian dwords (zero padded behind the data)
+    uint32_t ndw, next;        // dwords available / next dword to load
+    uint64_t acc;              // unread bits, left aligned
+    int n;                     // how many
+    uint32_t used;             // bits consumed
+    __device__ __forceinline__ void fill() {
+        if (n <= 32) { const uint32_t d = next < ndw ? be32(p[next]) : 0u; next++; acc |= (uint64_t)d << (32 - n); n += 32; }
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t k) {    // readBits (k <= 16; 0 bits = 0)
+        fill();
+        const uint32_t v = k ? (uint32_t)(acc >> (64 - k)) : 0u;
+        acc <<= k; n -= (int)k; used += k;
+        return v;
+    }
+};
+// scanSymbol (main.go:1297-1316) by table lookup; returns 0x100 for a code the table does not have
+__device__ __forceinline__ uint32_t pscan_symbol(PBits& br, const uint32_t* __restrict__ lut) {
+    br.fill();
+    uint32_t e = lut[(uint32_t)(br.acc >> (64 - JD_LUT_BITS))];
+    if (e & 0x80000000u) e = lut[(e & 0x7FFFFFFFu) + ((uint32_t)(br.acc >> (64 - JD_LUT_BITS - 6)) & 63u)];
+    if (e == 0) return 0x100u;
+    const uint32_t len = e >> 8;
+    br.acc <<= len; br.n -= (int)len; br.used += len;
+    return e & 0xFFu;
+}
+__device__ __forceinline__ int pextend(uint32_t v, uint32_t len) {   // main.go:248-250 / 292-294
+    return (len != 0 && v < (1u << (len - 1))) ? (int)v - (int)((1u << len) - 1u) : (int)v;
+}
+
+// one block of one scan: `blk` = the block's 64 coefficients in zig-zag order (cmap[index] in the Go code is the natural
+// position of zig-zag index `index`; this buffer is kept in zig-zag order, so index addresses it directly)
+__device__ __forceinline__ uint32_t pscan_block(const JdPScan& sc, PBits& br, const uint32_t* dcl, const uint32_t* acl, int& prev_dc,
+                                                uint32_t& skips, int16_t* __restrict__ blk) {
+    const uint32_t ss = sc.ss, se = sc.se, al = sc.al;
+    uint32_t err = 0;
+    auto put = [&](uint32_t i, int v) { if (v != (int)(short)v) err |= JD_ST_COEF; blk[i] = (int16_t)v; };
+    if (ss == 0 && sc.ah == 0) {                               // DC first visit, main.go:243-253
+        const uint32_t sym = pscan_symbol(br, dcl);
+        if (sym > 16u) return JD_ST_HUFF;
+        const int v = pextend(br.get(sym), sym) + prev_dc;
+        prev_dc = v;
+        put(0, v << al);
+    } else if (ss != 0 && sc.ah == 0) {                        // AC first visit, main.go:254-311
+        if (skips > 0) { skips -= 1; return 0; }
+        uint32_t index = ss;
+        while (index <= se) {
+            const uint32_t sym = pscan_symbol(br, acl);
+            if (sym > 0xFFu) return JD_ST_HUFF;
+            if (sym == 0xF0u) {                                // sixteen zeros (already zero: first visit)
+                if (index + 16u > 64u) return JD_ST_COEF;
+                index += 16u;
+            } else {
+                const uint32_t zeros = sym >> 4, len = sym & 15u;
+                if (len != 0) {
+                    index += zeros;
+                    if (index > 63u) return JD_ST_COEF;
+                    put(index, pextend(br.get(len), len) << al);
+                    index++;
+                } else {                                       // EOBn: this block is done, the next `skips` blocks too
+                    skips = ((1u << zeros) - 1u) + br.get(zeros);
+                    return err;
+                }
+            }
+        }
+    } else if (ss == 0) {                                      // DC refinement, main.go:312-320
+        blk[0] = (int16_t)(blk[0] | (int)(br.get(1) << al));
+    } else {                                                   // AC refinement, main.go:321-427
+        const int positive = 1 << al, negative = -(1 << al);
+        auto refine = [&](uint32_t i) {                        // a correction bit for every coefficient that is already non-zero
+            const int cur = blk[i];
+            if (br.get(1)) put(i, cur >= 0 ? cur + positive : cur + negative);
+        };
+        uint32_t index = ss;
+        if (skips == 0) {
+            while (index <= se) {
+                const uint32_t sym = pscan_symbol(br, acl);
+                if (sym > 0xFFu) return JD_ST_HUFF;
+                uint32_t zeroes = sym >> 4;
+                const uint32_t len = sym & 15u;
+                int coeff = 0;
+                if (len != 0) {
+                    if (len != 1) return JD_ST_COEF;
+                    coeff = br.get(1) ? positive : negative;
+                }
+                if (len == 0 && sym != 0xF0u) { skips = (1u << zeroes) + br.get(zeroes); break; }
+                for (;;) {                                     // main.go:369-394
+                    if (index > 63u) return JD_ST_COEF;
+                    if (blk[index] != 0) refine(index);
+                    else { if (zeroes == 0) break; zeroes -= 1; }
+                    index += 1;
+                }
+                blk[index] = (int16_t)coeff;
+                index += 1;
+            }
+        }
+        if (skips > 0) {
+            for (; index <= se; index++) if (blk[index] != 0) refine(index);
+            skips -= 1;
+        }
+    }
+    return err;
+}
+
+__global__ __launch_bounds__(64) void kp_scan(JdKernelArgs a, const JdPScan* __restrict__ scans, const uint32_t* __restrict__ list,
+                                               int n, const uint8_t* __restrict__ pstream, const uint32_t* __restrict__ plut) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n) return;
+    const JdPScan sc = scans[list[t]];
+    const JdImg& im = a.imgs[sc.img];
+    PBits br;
+    br.p = reinterpret_cast<const uint32_t*>(pstream + sc.stream_off); br.ndw = (sc.stream_len + 3u) >> 2; br.next = 0;
+    br.acc = 0; br.n = 0; br.used = 0;
+    int16_t* const cf = a.coef + im.coef_off;
+    const uint32_t hs = im.hs, vs = im.vs, nl = hs * vs;
+    const uint32_t bw = (im.width + 7u) >> 3, bh = (im.height + 7u) >> 3;          // main.go:160-161
+    // decodeHuffmanData, main.go:753-770: a scan of the first component alone walks its blocks in raster order, anything
+    // else walks the MCU grid
+    const bool lum_only = sc.ncomp == 1 && sc.comp[0] == 0;
+    const uint32_t xstep = lum_only ? 1u : hs, ystep = lum_only ? 1u : vs;
+    int prev_dc[3] = { 0, 0, 0 };
+    uint32_t skips = 0, err = 0;
+    for (uint32_t y = 0; y < bh && !err; y += ystep)
+        for (uint32_t x = 0; x < bw && !err; x += xstep)
+            for (uint32_t k = 0; k < sc.ncomp && !err; k++) {
+                const uint32_t cp = sc.comp[k];
+                const uint32_t* dcl = plut + (sc.dc_lut[k] == 0xFFFFFFFFu ? 0u : sc.dc_lut[k]);
+                const uint32_t* acl = plut + (sc.ac_lut[k] == 0xFFFFFFFFu ? 0u : sc.ac_lut[k]);
+                const uint32_t umax = (lum_only || cp) ? 1u : vs, vmax = (lum_only || cp) ? 1u : hs;
+                for (uint32_t u = 0; u < umax && !err; u++)
+                    for (uint32_t v = 0; v < vmax && !err; v++) {
+                        const uint32_t bx = x + v, by = y + u;
+                        const uint32_t mcu = (by / vs) * im.mcux + bx / hs;
+                        const uint32_t b = cp ? nl + cp - 1u : (by % vs) * hs + bx % hs;
+                        err |= pscan_block(sc, br, dcl, acl, prev_dc[cp], skips, cf + ((uint64_t)mcu * im.bpm + b) * 64u);
+                    }
+            }
+    if (br.used > sc.stream_len * 8u) err |= JD_ST_TRUNC;                        // readBit -1 (main.go:1273)
+    if (err) atomicOr(&a.status[sc.img], err);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: dequantise + de-zigzag + IDCT + chroma spread + colour conversion
 // ------------------------------------------------------------------------------------------------
 struct ZZTables { int n2z[64]; };
@@ -1309,6 +1459,12 @@ void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s) {
 
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k1_dc_scan, dim3(a.n_images * 3), dim3(1024), 0, s, a);
+}
+
+void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
+                      const uint32_t* d_plut, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(kp_scan, dim3((n + 63) / 64), dim3(64), 0, s, a, d_scans, d_list, n, d_pstream, d_plut);
 }
 
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {

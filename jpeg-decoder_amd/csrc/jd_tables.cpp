@@ -157,3 +157,38 @@ int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool i
     }
     return 0;
 }
+
+int jd_pack_lut_sym(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint32_t>& out) {
+    int count = 0;
+    for (int i = 0; i < 16; i++) count += bits[i];
+    if (count != nvals || nvals > 256) return -1;
+    const size_t base = out.size();
+    out.resize(base + JD_LUT_PRIMARY, 0);
+    unsigned code = 0;
+    int k = 0;
+    for (unsigned len = 1; len <= 16; len++) {
+        for (int i = 0; i < bits[len - 1]; i++, k++) {
+            if (code >= (1u << len)) return -2;
+            const uint32_t e = (uint32_t)vals[k] | (len << 8);
+            if (len <= JD_LUT_BITS) {
+                const unsigned first = code << (JD_LUT_BITS - len), n = 1u << (JD_LUT_BITS - len);
+                for (unsigned j = 0; j < n; j++) out[base + first + j] = e;
+            } else {
+                const unsigned prefix = code >> (len - JD_LUT_BITS);
+                uint32_t p = out[base + prefix];
+                if (!(p & 0x80000000u)) {
+                    if (p != 0) return -2;
+                    const size_t off = out.size() - base;
+                    out.resize(out.size() + JD_LUT_SECONDARY, 0);
+                    p = 0x80000000u | (uint32_t)off;
+                    out[base + prefix] = p;
+                }
+                const unsigned sub = (code << (JD_LUT_BITS + 6 - len)) & 63u, n = 1u << (JD_LUT_BITS + 6 - len);
+                for (unsigned j = 0; j < n; j++) out[base + (p & 0x7FFFFFFFu) + sub + j] = e;
+            }
+            code++;
+        }
+        code <<= 1;
+    }
+    return 0;
+}

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (written by profiles/collect.sh) into the committed summaries under profiles/:
-   <tag>_<wl>_kernel_stats.csv, <tag>_<wl>_bench.json, <tag>_<wl>_bench_under_rocprof.json and <tag>_traffic.json.
+   <tag>_<wl>_kernel_stats.csv, <tag>_<wl>_bench.json, <tag>_<wl>_bench_under_rocprof.json, <tag>_traffic.json
+   (also copied to r02_traffic.json, which bench.py reads) and <tag>_sq_counters.json.
 
-HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950 FETCH_SIZE tallies
-128-byte fabric reads at 64 bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section), so it is doubled; WRITE_SIZE is exact.
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950 FETCH_SIZE tallies 128-byte
+fabric reads at 64 bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section), so it is doubled; WRITE_SIZE is exact.  Counters
+are averaged per launch and multiplied by the launches of that kernel in one step (k1_sync runs three times a step).
 """
 import csv
 import glob
@@ -17,20 +19,34 @@ root = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(root, "..", "gpurun_out", tag)
 
 
-def per_kernel(path):
-    acc = {}
+def per_kernel(path, by_counter=False):
+    """-> {kernel: mean counter value per launch} (or {kernel: {counter: mean}}) and {kernel: launches seen}"""
+    acc, launches = {}, {}
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"].split("(")[0]
             if not name.startswith("k"):
                 continue
-            a = acc.setdefault(name, [0.0, 0])
+            key = (name, row["Counter_Name"]) if by_counter else name
+            a = acc.setdefault(key, [0.0, 0])
             a[0] += float(row["Counter_Value"])
             a[1] += 1
-    return {k: v[0] / v[1] for k, v in acc.items()}
+            launches.setdefault(name, set()).add(row["Dispatch_Id"])
+    mean = {k: v[0] / v[1] for k, v in acc.items()}
+    if by_counter:
+        out = {}
+        for (name, c), v in mean.items():
+            out.setdefault(name, {})[c] = v
+        mean = out
+    return mean, {k: len(v) for k, v in launches.items()}
 
 
 traffic = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "workloads": {}}
+sq = {"note": "SQ counters per launch (mean over the launches of the profiled run; rocprofv3 sums over the XCDs). "
+              "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); "
+              "SQ_BUSY_CYCLES comes out as 128 x the kernel's duration (checked against the kernel trace at ~2.1 GHz), i.e. it "
+              "is summed over 128 counter instances, and the chip has 1024 SIMDs, so valu_busy = SQ_ACTIVE_INST_VALU / "
+              "(8 * SQ_BUSY_CYCLES) is the share of SIMD-cycles in which a vector instruction was executing.", "workloads": {}}
 for wl in ("c3", "c4", "c5"):
     st = glob.glob(os.path.join(src, "stats_" + wl, "*", "*_kernel_stats.csv"))
     if st:
@@ -43,12 +59,34 @@ for wl in ("c3", "c4", "c5"):
     wr = glob.glob(os.path.join(src, "pmc_write_" + wl, "*", "*_counter_collection.csv"))
     if not (fe and wr):
         continue
-    f, w = per_kernel(fe[0]), per_kernel(wr[0])
+    (f, nl), (w, _) = per_kernel(fe[0]), per_kernel(wr[0])
     bench = json.load(open(os.path.join(src, "pmc_fetch_%s.json" % wl)))
+    steps = bench["steps"] + bench["warmup"]
+    per_step = {k: max(1, round(nl[k] / steps)) for k in nl}
     traffic["workloads"][wl] = {
-        "batch": bench["config"]["images_per_gpu_per_step"],
-        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-        "kernels": {k: {"FETCH_SIZE_KiB": round(f[k]), "WRITE_SIZE_KiB": round(w.get(k, 0)),
-                        "hbm_bytes_per_launch": int((2 * f[k] + w.get(k, 0)) * 1024)} for k in sorted(f)}}
+        "images_per_step": bench["config"]["images_per_gpu_per_step"],
+        "algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "kernels": {k: {"FETCH_SIZE_KiB_per_launch": round(f[k]), "WRITE_SIZE_KiB_per_launch": round(w.get(k, 0)),
+                        "launches_per_step": per_step[k],
+                        "hbm_bytes_per_step": int((2 * f[k] + w.get(k, 0)) * 1024 * per_step[k])} for k in sorted(f)}}
+    traffic["workloads"][wl]["hbm_bytes_per_step_all_kernels"] = sum(v["hbm_bytes_per_step"] for v in traffic["workloads"][wl]["kernels"].values())
+    cs = {}
+    for part in ("sq1_", "sq2_"):
+        g = glob.glob(os.path.join(src, part + wl, "*", "*_counter_collection.csv"))
+        if g:
+            m, _ = per_kernel(g[0], by_counter=True)
+            for k, d in m.items():
+                cs.setdefault(k, {}).update({c: round(v) for c, v in d.items()})
+    for k, d in cs.items():
+        if d.get("SQ_BUSY_CYCLES"):
+            d["valu_busy"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) / (8.0 * d["SQ_BUSY_CYCLES"]), 3)
+            d["kernel_cycles"] = round(d["SQ_BUSY_CYCLES"] * 4 / 128)
+        if d.get("SQ_WAVES"):
+            d["valu_insts_per_wave"] = round(d.get("SQ_INSTS_VALU", 0) / d["SQ_WAVES"], 1)
+    if cs:
+        sq["workloads"][wl] = cs
 json.dump(traffic, open(os.path.join(root, tag + "_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(root, "r02_traffic.json"), "w"), indent=1)
+json.dump(sq, open(os.path.join(root, tag + "_sq_counters.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
+print(json.dumps(sq, indent=1))
