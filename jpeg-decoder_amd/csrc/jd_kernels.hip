@@ -1181,9 +1181,6 @@ __device__ __forceinline__ uint32_t put_u8(float v, uint32_t sel, uint32_t old) 
     return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(v), sel, old);
 }
 
-// (a variant that kept the column pass's truncated outputs in fp64 -- v_trunc_f64 instead of the
-// i32 round trip -- needs 156 VGPRs and measured 30 % slower on MI355X; the int form stays)
-
 // ---- K2, MCU-per-lane form -----------------------------------------------------------------------------
 // One lane owns one whole MCU, one wave owns 64 consecutive MCUs; waves never talk to each other: no LDS, no
 // barrier.  The lane runs the chroma blocks first and keeps their samples in registers (packed int16), then
@@ -1250,10 +1247,12 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
         // arrive through the vector-memory path and are not ordered behind ds_read)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (st + 1u < BPM) fetch(st + 1u);
+        // column pass; its outputs are truncated to int as the reference does (main.go:521-528).  (Keeping them in fp64
+        // with trunc() would save the 64 conversions back, but 128 registers of intermediates spill: 162 VGPRs spilled.)
         int mid[64];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            int x[8], o[8];
+            int x[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int zi = kZZ.n2z[r * 8 + j];
@@ -1261,31 +1260,28 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 const int qv = (int)((qw[(r * 8 + j) >> 2] >> (((r * 8 + j) & 3) * 8)) & 0xFFu);
                 x[r] = __mul24(cv, qv);                             // dequantize, main.go:660-662
             }
+            int o[8];
             idct_1d(K, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
 #pragma unroll
             for (int r = 0; r < 8; r++) mid[r * 8 + j] = o[r];
         }
-        uint32_t smp[32];                                          // the block's samples, saturated int16 pairs
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int o[8];
+        // a row of the row pass is consumed at once (packed as a chroma sample row, or colour-converted as a luma row)
+        auto row_pass = [&](int i, int (&o)[8]) {
             idct_1d(K, mid[i * 8 + 0], mid[i * 8 + 1], mid[i * 8 + 2], mid[i * 8 + 3], mid[i * 8 + 4], mid[i * 8 + 5],
                     mid[i * 8 + 6], mid[i * 8 + 7], o);
-            typedef short short2v __attribute__((ext_vector_type(2)));
+        };
+        if (b >= NL) {                                             // wave-uniform: a chroma block's samples wait in registers
+#pragma unroll                                                     // as saturated int16 pairs (exact for every stream an
+            for (int i = 0; i < 8; i++) {                          // 8-bit encoder can make)
+                int o[8];
+                row_pass(i, o);
+                typedef short short2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                union { short2v s; uint32_t u; } p;
-                p.s = __builtin_amdgcn_cvt_pk_i16(o[2 * k], o[2 * k + 1]);
-                smp[i * 4 + k] = p.u;
-            }
-        }
-        if (b >= NL) {                                             // wave-uniform
-            if (b == NL) {
-#pragma unroll
-                for (int i = 0; i < 32; i++) chroma[0][i] = smp[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 32; i++) chroma[1][i] = smp[i];
+                for (int k = 0; k < 4; k++) {
+                    union { short2v s; uint32_t u; } p;
+                    p.s = __builtin_amdgcn_cvt_pk_i16(o[2 * k], o[2 * k + 1]);
+                    if (b == NL) chroma[0][i * 4 + k] = p.u; else chroma[1][i * 4 + k] = p.u;
+                }
             }
             continue;
         }
@@ -1298,7 +1294,6 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
 #pragma unroll
         for (uint32_t yb = 0; yb < NL; yb++) {
             if (b == yb) {                                         // wave-uniform; static register indices inside
-                constexpr int dummy = 0; (void)dummy;
                 const uint32_t bx = yb % HS, by = yb / HS;
 #pragma unroll
                 for (int c = 0; c < 2; c++)
@@ -1332,14 +1327,15 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
             for (int h = 0; h < 2; h++) {
                 const int i = 2 * r + h;
                 const uint32_t Yp = Y0 + by * 8u + (uint32_t)i;
+                int ys[8];                                         // row i of the luma block, straight from the row pass
+                row_pass(i, ys);
                 uint32_t d[6] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     // the two pixels that share chroma sample k, as one packed-f32 pair: the same additions in the same
                     // order as main.go:679-703, two at a time
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const uint32_t yw = smp[i * 4 + k];
-                    const f32x2 y = { (float)(int)(short)(yw & 0xFFFFu), (float)((int)yw >> 16) };
+                    const f32x2 y = { (float)ys[2 * k], (float)ys[2 * k + 1] };
                     const f32x2 off = { 128.0f, 128.0f };
                     const f32x2 R = (y + f32x2{ rc[k], rc[k] }) + off;
                     const f32x2 G = ((y - f32x2{ gb[k], gb[k] }) - f32x2{ gr[k], gr[k] }) + off;
