@@ -212,6 +212,8 @@ def main():
                 b.bind_ecs(k, e.data_ptr(), lens[k])
                 b.bind_rgb(k, rgb[k].data_ptr(), w * 3)
             batches.append((b, rgb))
+        torch.cuda.synchronize()                               # the copies above ran on torch's default stream
+
         def step():
             for k, (b, _) in enumerate(batches):
                 b.run(tstreams[k % len(tstreams)].cuda_stream)
