@@ -225,6 +225,13 @@ int jd_parse_scans(const uint8_t* file, size_t file_len, jd_frame* frame, jd_sca
 /* Decode a file given as frame + scans (host memory in, host memory out; synchronous). */
 int jd_decode_scans(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file, size_t file_len,
                     uint8_t* rgb_out, size_t row_stride, int device);
+/* The same for n_images progressive files at once (the reference's file loop, main.go:1509-1512): the scans of all of
+ * them are dealt to wavefronts together, level by level -- a scan is a serial chain, so a batch is what fills the chip.
+ * status[i] (may be NULL) receives image i's own result; the call returns the first error.  row_strides may be NULL
+ * (3 * width).  Baseline files do not belong here (JD_E_UNSUPPORTED): they go through jd_batch_*. */
+int jd_decode_scans_batch(int n_images, const jd_frame* frames, const jd_scan* const* scans, const int* n_scans,
+                          const uint8_t* const* files, const size_t* file_lens, uint8_t* const* rgb_out,
+                          const size_t* row_strides, int* status, int device);
 /* Parity hook: the accumulated coefficients after the last scan, layout as jd_decode_coefficients. */
 int jd_decode_scans_coefficients(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file,
                                  size_t file_len, int16_t* coef_out, size_t coef_cap, int device);

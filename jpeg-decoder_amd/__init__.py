@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "jd_batch_timing", "jd_batch_stage_times", "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
     "jd_batch_stage_reserve", "jd_batch_stage_ecs", "jd_batch_stage_jpegs", "jd_batch_submit", "jd_batch_host_rgb",
     "jd_host_alloc", "jd_host_free", "jd_decode_resident", "jd_parse_scans", "jd_decode_scans", "jd_decode_scans_coefficients",
+    "jd_decode_scans_batch",
 ]
 
 
@@ -107,6 +108,8 @@ def _lib():
         L.jd_parse_scans.argtypes = [_vp, _sz, PF, PS, _ci, ctypes.POINTER(_ci)]
         L.jd_decode_scans.argtypes = [PF, PS, _ci, _vp, _sz, _vp, _sz, _ci]
         L.jd_decode_scans_coefficients.argtypes = [PF, PS, _ci, _vp, _sz, _vp, _sz, _ci]
+        L.jd_decode_scans_batch.argtypes = [_ci, PF, ctypes.POINTER(PS), ctypes.POINTER(_ci), ctypes.POINTER(_vp),
+                                            ctypes.POINTER(_sz), ctypes.POINTER(_vp), ctypes.POINTER(_sz), ctypes.POINTER(_ci), _ci]
         L.jd_host_alloc.argtypes = [_sz, ctypes.POINTER(_vp)]
         L.jd_host_free.argtypes = [_vp]
         L.jd_host_free.restype = None
@@ -185,6 +188,27 @@ def decode_progressive(data, device=0, coefficients=False):
     _check(_lib().jd_decode_scans(ctypes.byref(fr), scans, n, a.ctypes.data, a.size, out.ctypes.data, fr.width * 3, device),
            "jd_decode_scans")
     return out
+
+
+def decode_progressive_batch(files, device=0):
+    """jd_decode_scans_batch: many progressive files in one call.  -> (list of RGB arrays, list of per-image status codes)"""
+    _ensure_init()
+    n = len(files)
+    arrs = [_as_u8(f) for f in files]
+    parsed = [parse_scans(a) for a in arrs]
+    frames = (Frame * n)(*[p[0] for p in parsed])
+    PS = ctypes.POINTER(Scan)
+    scans = (PS * n)(*[ctypes.cast(p[1], PS) for p in parsed])
+    counts = (_ci * n)(*[p[2] for p in parsed])
+    ptrs = (_vp * n)(*[a.ctypes.data for a in arrs])
+    lens = (_sz * n)(*[a.size for a in arrs])
+    outs = [np.empty((p[0].height, p[0].width, 3), np.uint8) for p in parsed]
+    optrs = (_vp * n)(*[o.ctypes.data for o in outs])
+    status = (_ci * n)()
+    rc = _lib().jd_decode_scans_batch(n, frames, scans, counts, ptrs, lens, optrs, None, status, device)
+    if rc != 0 and all(s == 0 for s in status):
+        raise JpegHipError(rc, "jd_decode_scans_batch")
+    return outs, list(status)
 
 
 def decode_jpeg(data, device=0):

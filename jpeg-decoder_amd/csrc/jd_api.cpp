@@ -33,7 +33,7 @@ void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, ui
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, const JdIdctConst& K, hipStream_t s);
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
-                      const uint32_t* d_plut, hipStream_t s);
+                      const uint32_t* d_plut, uint32_t max_lut_bytes, hipStream_t s);
 int jdk_static_scratch(void** ptr, size_t* bytes);
 }
 
@@ -793,7 +793,10 @@ extern "C" int jd_batch_download(jd_batch* b, int image, uint8_t* rgb_out, size_
     const JdImg& im = b->img[image];
     if (row_stride < (size_t)im.width * 3 || !im.rgb) return JD_E_ARG;
     HIPCHK(hipSetDevice(b->device));
-    HIPCHK(hipMemcpy2DAsync(rgb_out, row_stride, im.rgb, im.row_stride, (size_t)im.width * 3, im.height, hipMemcpyDeviceToHost, b->stream));
+    if (row_stride == im.row_stride)                         // one copy (the 2-D form goes row by row)
+        HIPCHK(hipMemcpyAsync(rgb_out, im.rgb, (size_t)(im.height - 1) * row_stride + (size_t)im.width * 3, hipMemcpyDeviceToHost, b->stream));
+    else
+        HIPCHK(hipMemcpy2DAsync(rgb_out, row_stride, im.rgb, im.row_stride, (size_t)im.width * 3, im.height, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return JD_OK;
 }
@@ -1010,95 +1013,114 @@ struct DevBuf {                       // hipMalloc'ed scratch of one call
     int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 256))); return JD_OK; }
 };
 
-int decode_scans_impl(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file, size_t file_len,
-                      uint8_t* rgb_out, size_t row_stride, int16_t* coef_out, size_t coef_cap, int device) {
-    if (!frame || !scans || n_scans <= 0 || !file) return JD_E_ARG;
-    Geometry g; int rc = frame_geometry(frame, &g);
-    if (rc) return rc;
-    if (!scans[0].progressive) {                               // an SOF0 file: the baseline path
-        if (n_scans != 1 || scans[0].ecs_off + scans[0].ecs_len > file_len) return JD_E_ARG;
-        return coef_out ? jd_decode_coefficients(frame, file + scans[0].ecs_off, scans[0].ecs_len, 1, nullptr, 0, coef_out, coef_cap, device)
-                        : jd_decode(frame, file + scans[0].ecs_off, scans[0].ecs_len, 1, nullptr, 0, rgb_out, row_stride, device);
+// unstuff one scan (main.go:993-1021) at memchr speed: runs between FF bytes are copied whole
+int unstuff_scan(const uint8_t* e, size_t n, std::vector<uint8_t>& out) {
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t* q = (const uint8_t*)memchr(e + i, 0xFF, n - i);
+        const size_t j = q ? (size_t)(q - e) : n;
+        out.insert(out.end(), e + i, e + j);
+        if (j + 1 >= n) break;                                 // (the parser ends the extent in front of the closing marker)
+        const uint8_t nx = e[j + 1];
+        if (nx == 0x00) { out.push_back(0xFF); i = j + 2; }
+        else if (nx >= 0xD0 && nx <= 0xD7) i = j + 2;          // RSTn: dropped
+        else if (nx == 0xFF) i = j + 1;                        // fill byte
+        else return JD_E_MARKER;
     }
-    for (int c = 0; c < frame->ncomp; c++)
-        if (frame->comp[c].tq > 3 || !(frame->qt_present & (1u << frame->comp[c].tq))) return JD_E_TABLE;
-    // ---- per scan: unstuffed bytes, tables, descriptor ----
+    return JD_OK;
+}
+
+// n_images progressive files in one go: the scans of all of them are dealt to waves level by level, so a batch keeps the
+// chip busy where one file cannot (a scan is a serial chain).
+int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const* scans, const int* n_scans,
+                      const uint8_t* const* files, const size_t* file_lens, uint8_t* const* rgb_out, const size_t* row_strides,
+                      int16_t* coef_out, size_t coef_cap, int* status_out, int device) {
+    if (n_images <= 0 || !frames || !scans || !n_scans || !files || !file_lens) return JD_E_ARG;
+    if (coef_out && n_images != 1) return JD_E_ARG;
     std::vector<uint8_t> stream;
-    std::vector<uint32_t> lut(1, 0);                           // entry 0 stays unused (offset 0 = "no table" is never read)
-    std::vector<JdPScan> ps(n_scans);
-    std::vector<int> level(n_scans, 0);
+    std::vector<uint32_t> lut(1, 0);                           // entry 0 stays unused
+    std::vector<JdPScan> ps;
+    std::vector<int> level;
     int n_levels = 0;
-    for (int k = 0; k < n_scans; k++) {
-        const jd_scan& sc = scans[k];
-        if (!sc.progressive || sc.ncomp < 1 || sc.ncomp > frame->ncomp || sc.se > 63 || sc.ss > sc.se || sc.al > 13) return JD_E_ARG;
-        if (sc.ecs_off > file_len || sc.ecs_len > file_len - sc.ecs_off) return JD_E_ARG;
-        if (sc.ss == 0 && sc.se != 0) return JD_E_UNSUPPORTED; // T.81 G.1.1.1.1: a DC scan holds DC only (the reference would mix the cases up)
-        if (sc.ss != 0 && sc.ncomp != 1) return JD_E_UNSUPPORTED;   // AC scans are never interleaved (the reference's skips counter assumes it)
-        JdPScan& d = ps[k];
-        memset(&d, 0, sizeof d);
-        d.img = 0; d.ss = sc.ss; d.se = sc.se; d.ah = sc.ah; d.al = sc.al; d.ncomp = sc.ncomp;
-        // the reference walks the FRAME's components and decodes those the scan uses (main.go:771-775): ascending order
-        int order[3] = { 0, 1, 2 };
-        std::sort(order, order + sc.ncomp, [&](int p, int q) { return sc.comp[p] < sc.comp[q]; });
-        for (int j = 0; j < sc.ncomp; j++) {
-            const int src = order[j];
-            if (sc.comp[src] >= frame->ncomp || (j && sc.comp[src] == sc.comp[order[j - 1]])) return JD_E_ARG;
-            d.comp[j] = sc.comp[src]; d.dc_lut[j] = d.ac_lut[j] = 0xFFFFFFFFu;
-            const bool need_dc = sc.ss == 0 && sc.ah == 0, need_ac = sc.ss != 0;
-            if (need_dc) {
-                if (sc.td[src] > 3 || !sc.huff[0][sc.td[src]].present) return JD_E_TABLE;
-                const jd_huff& h = sc.huff[0][sc.td[src]];
-                d.dc_lut[j] = (uint32_t)lut.size();
-                if (jd_pack_lut_sym(h.bits, h.vals, h.nvals, lut)) return JD_E_TABLE;
+    uint32_t max_lut_bytes = 0;                                // symbol tables of one scan (they sit in LDS beside the stream window)
+    std::vector<jd_frame> fr(frames, frames + n_images);
+    for (int im = 0; im < n_images; im++) {
+        const jd_frame* frame = &frames[im];
+        const jd_scan* sc_im = scans[im];
+        const uint8_t* file = files[im];
+        const size_t file_len = file_lens[im];
+        if (!sc_im || n_scans[im] <= 0 || !file) return JD_E_ARG;
+        Geometry g; int rc = frame_geometry(frame, &g);
+        if (rc) return rc;
+        for (int c = 0; c < frame->ncomp; c++)
+            if (frame->comp[c].tq > 3 || !(frame->qt_present & (1u << frame->comp[c].tq))) return JD_E_TABLE;
+        const size_t first = ps.size();
+        for (int k = 0; k < n_scans[im]; k++) {
+            const jd_scan& sc = sc_im[k];
+            if (!sc.progressive) return n_images == 1 ? JD_E_ARG : JD_E_UNSUPPORTED;   // baseline files: the jd_batch path
+            if (sc.ncomp < 1 || sc.ncomp > frame->ncomp || sc.se > 63 || sc.ss > sc.se || sc.al > 13) return JD_E_ARG;
+            if (sc.ecs_off > file_len || sc.ecs_len > file_len - sc.ecs_off) return JD_E_ARG;
+            if (sc.ss == 0 && sc.se != 0) return JD_E_UNSUPPORTED; // T.81 G.1.1.1.1: a DC scan holds DC only (the reference would mix the cases up)
+            if (sc.ss != 0 && sc.ncomp != 1) return JD_E_UNSUPPORTED;   // AC scans are never interleaved (the reference's skips counter assumes it)
+            JdPScan d;
+            uint32_t scan_lut_bytes = 0;
+            memset(&d, 0, sizeof d);
+            d.img = (uint32_t)im; d.ss = sc.ss; d.se = sc.se; d.ah = sc.ah; d.al = sc.al; d.ncomp = sc.ncomp;
+            // the reference walks the FRAME's components and decodes those the scan uses (main.go:771-775): ascending order
+            int order[3] = { 0, 1, 2 };
+            std::sort(order, order + sc.ncomp, [&](int p, int q) { return sc.comp[p] < sc.comp[q]; });
+            for (int j = 0; j < sc.ncomp; j++) {
+                const int src = order[j];
+                if (sc.comp[src] >= frame->ncomp || (j && sc.comp[src] == sc.comp[order[j - 1]])) return JD_E_ARG;
+                d.comp[j] = sc.comp[src]; d.lut_off[j] = d.lut_len[j] = 0;
+                const bool need_dc = sc.ss == 0 && sc.ah == 0, need_ac = sc.ss != 0;
+                if (need_dc || need_ac) {
+                    const int id = need_dc ? sc.td[src] : sc.ta[src];
+                    if (id > 3 || !sc.huff[need_dc ? 0 : 1][id].present) return JD_E_TABLE;
+                    const jd_huff& h = sc.huff[need_dc ? 0 : 1][id];
+                    d.lut_off[j] = (uint32_t)lut.size();
+                    if (jd_pack_lut_sym(h.bits, h.vals, h.nvals, lut)) return JD_E_TABLE;
+                    d.lut_len[j] = (uint32_t)lut.size() - d.lut_off[j];
+                    scan_lut_bytes += d.lut_len[j] * 4u;
+                }
             }
-            if (need_ac) {
-                if (sc.ta[src] > 3 || !sc.huff[1][sc.ta[src]].present) return JD_E_TABLE;
-                const jd_huff& h = sc.huff[1][sc.ta[src]];
-                d.ac_lut[j] = (uint32_t)lut.size();
-                if (jd_pack_lut_sym(h.bits, h.vals, h.nvals, lut)) return JD_E_TABLE;
+            max_lut_bytes = std::max(max_lut_bytes, scan_lut_bytes);
+            while (stream.size() % 16) stream.push_back(0);
+            if (stream.size() + sc.ecs_len + 64 >= (size_t)1 << 31) return JD_E_ARG;
+            d.stream_off = (uint32_t)stream.size();
+            rc = unstuff_scan(file + sc.ecs_off, sc.ecs_len, stream);
+            if (rc) return rc;
+            d.stream_len = (uint32_t)(stream.size() - d.stream_off);
+            stream.insert(stream.end(), 16, 0);
+            // dependency level: after every earlier scan of the file that touches one of its components in an overlapping band
+            int lv = 0;
+            for (int i = 0; i < k; i++) {
+                bool share = false;
+                for (int p = 0; p < sc.ncomp; p++) for (int q = 0; q < sc_im[i].ncomp; q++) share |= sc.comp[p] == sc_im[i].comp[q];
+                if (share && !(sc.se < sc_im[i].ss || sc_im[i].se < sc.ss)) lv = std::max(lv, level[first + i] + 1);
             }
+            ps.push_back(d); level.push_back(lv);
+            n_levels = std::max(n_levels, lv + 1);
         }
-        // unstuff (main.go:993-1021)
-        while (stream.size() % 16) stream.push_back(0);
-        d.stream_off = (uint32_t)stream.size();
-        const uint8_t* e = file + sc.ecs_off;
-        for (size_t i = 0; i < sc.ecs_len; i++) {
-            if (e[i] != 0xFF) { stream.push_back(e[i]); continue; }
-            if (i + 1 >= sc.ecs_len) break;                    // (the parser ends the extent in front of the closing marker)
-            const uint8_t nx = e[i + 1];
-            if (nx == 0x00) { stream.push_back(0xFF); i++; }
-            else if (nx >= 0xD0 && nx <= 0xD7) i++;            // RSTn: dropped
-            else if (nx == 0xFF) continue;                     // fill byte
-            else return JD_E_MARKER;
-        }
-        d.stream_len = (uint32_t)(stream.size() - d.stream_off);
-        for (int z = 0; z < 16; z++) stream.push_back(0);
-        // dependency level: after every earlier scan that touches one of its components in an overlapping band
-        for (int i = 0; i < k; i++) {
-            bool share = false;
-            for (int p = 0; p < sc.ncomp; p++) for (int q = 0; q < scans[i].ncomp; q++) share |= sc.comp[p] == scans[i].comp[q];
-            if (share && !(sc.se < scans[i].ss || scans[i].se < sc.ss)) level[k] = std::max(level[k], level[i] + 1);
-        }
-        n_levels = std::max(n_levels, level[k] + 1);
+        // the batch needs SOME valid table pair per component; K0 / K1 never run on these images
+        memset(fr[im].huff, 0, sizeof fr[im].huff);
+        fr[im].huff[0][0].bits[0] = 1; fr[im].huff[0][0].nvals = 1; fr[im].huff[0][0].present = 1;
+        fr[im].huff[1][0] = fr[im].huff[0][0];
+        for (int c = 0; c < fr[im].ncomp; c++) fr[im].comp[c].td = fr[im].comp[c].ta = 0;
+        fr[im].restart_interval = 0;
     }
-    if (stream.size() >= (size_t)1 << 31) return JD_E_ARG;
-    // ---- device: a one-image batch supplies geometry, quantisation tables, coefficient buffer and K2 ----
-    jd_frame fr = *frame;                                      // the batch needs SOME valid table pair per component; K0/K1 never run
-    memset(fr.huff, 0, sizeof fr.huff);
-    fr.huff[0][0].bits[0] = 1; fr.huff[0][0].nvals = 1; fr.huff[0][0].present = 1;
-    fr.huff[1][0] = fr.huff[0][0];
-    for (int c = 0; c < fr.ncomp; c++) fr.comp[c].td = fr.comp[c].ta = 0;
-    fr.restart_interval = 0;
+    if (max_lut_bytes > 60u * 1024u) return JD_E_TABLE;
+    // ---- device: a batch supplies geometry, quantisation tables, coefficient buffers and K2 ----
     jd_batch* b = nullptr;
-    size_t cap1 = 16;
-    rc = jd_batch_create(device, 1, &fr, &cap1, JD_BATCH_KEEP_COEF, &b);
+    std::vector<size_t> caps(n_images, 16);
+    int rc = jd_batch_create(device, n_images, fr.data(), caps.data(), JD_BATCH_KEEP_COEF, &b);
     if (rc) return rc;
     struct Guard { jd_batch* b; ~Guard() { batch_release(b); } } guard{ b };
     DevBuf d_stream, d_lut, d_scans, d_list;
     std::vector<uint32_t> list;
     std::vector<int> level_start(n_levels + 1, 0);
     for (int l = 0; l < n_levels; l++) {
-        for (int k = 0; k < n_scans; k++) if (level[k] == l) list.push_back((uint32_t)k);
+        for (size_t k = 0; k < ps.size(); k++) if (level[k] == l) list.push_back((uint32_t)k);
         level_start[l + 1] = (int)list.size();
     }
     if ((rc = d_stream.alloc(stream.size())) || (rc = d_lut.alloc(lut.size() * 4)) || (rc = d_scans.alloc(ps.size() * sizeof(JdPScan))) ||
@@ -1114,25 +1136,46 @@ int decode_scans_impl(const jd_frame* frame, const jd_scan* scans, int n_scans, 
     const JdKernelArgs a = kernel_args(b);
     for (int l = 0; l < n_levels; l++)
         jdk_launch_pscan(a, (const JdPScan*)d_scans.p, (const uint32_t*)d_list.p + level_start[l], level_start[l + 1] - level_start[l],
-                         (const uint8_t*)d_stream.p, (const uint32_t*)d_lut.p, s);
+                         (const uint8_t*)d_stream.p, (const uint32_t*)d_lut.p, max_lut_bytes, s);
     HIPCHK(hipGetLastError());
     rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
     b->ran = true; b->last_stream = s;
-    rc = wait_on(b);                                           // synchronises: the pageable sources above are free again
-    if (rc) return rc;
-    return coef_out ? jd_batch_coefficients(b, 0, coef_out, coef_cap) : jd_batch_download(b, 0, rgb_out, row_stride);
+    const int first_err = wait_on(b);                          // synchronises: the pageable sources above are free again
+    if (first_err == JD_E_HIP) return first_err;
+    if (coef_out) return first_err ? first_err : jd_batch_coefficients(b, 0, coef_out, coef_cap);
+    for (int im = 0; im < n_images; im++) {
+        const int st = status_to_error(b->status[im]);
+        if (status_out) status_out[im] = st;
+        if (st == JD_OK && rgb_out && rgb_out[im]) { rc = jd_batch_download(b, im, rgb_out[im], row_strides ? row_strides[im] : (size_t)frames[im].width * 3); if (rc) return rc; }
+    }
+    return first_err;
 }
 
 }  // namespace
 
 extern "C" int jd_decode_scans(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file, size_t file_len,
                                uint8_t* rgb_out, size_t row_stride, int device) {
-    if (!rgb_out) return JD_E_ARG;
-    return decode_scans_impl(frame, scans, n_scans, file, file_len, rgb_out, row_stride, nullptr, 0, device);
+    if (!rgb_out || !frame || !scans || n_scans <= 0 || !file) return JD_E_ARG;
+    if (!scans[0].progressive) {                               // an SOF0 file: the baseline path
+        if (n_scans != 1 || scans[0].ecs_off > file_len || scans[0].ecs_len > file_len - scans[0].ecs_off) return JD_E_ARG;
+        return jd_decode(frame, file + scans[0].ecs_off, scans[0].ecs_len, 1, nullptr, 0, rgb_out, row_stride, device);
+    }
+    return decode_scans_impl(1, frame, &scans, &n_scans, &file, &file_len, &rgb_out, &row_stride, nullptr, 0, nullptr, device);
 }
 
 extern "C" int jd_decode_scans_coefficients(const jd_frame* frame, const jd_scan* scans, int n_scans, const uint8_t* file,
                                             size_t file_len, int16_t* coef_out, size_t coef_cap, int device) {
-    if (!coef_out) return JD_E_ARG;
-    return decode_scans_impl(frame, scans, n_scans, file, file_len, nullptr, 0, coef_out, coef_cap, device);
+    if (!coef_out || !frame || !scans || n_scans <= 0 || !file) return JD_E_ARG;
+    if (!scans[0].progressive) {
+        if (n_scans != 1 || scans[0].ecs_off > file_len || scans[0].ecs_len > file_len - scans[0].ecs_off) return JD_E_ARG;
+        return jd_decode_coefficients(frame, file + scans[0].ecs_off, scans[0].ecs_len, 1, nullptr, 0, coef_out, coef_cap, device);
+    }
+    return decode_scans_impl(1, frame, &scans, &n_scans, &file, &file_len, nullptr, nullptr, coef_out, coef_cap, nullptr, device);
+}
+
+extern "C" int jd_decode_scans_batch(int n_images, const jd_frame* frames, const jd_scan* const* scans, const int* n_scans,
+                                     const uint8_t* const* files, const size_t* file_lens, uint8_t* const* rgb_out,
+                                     const size_t* row_strides, int* status, int device) {
+    if (!rgb_out) return JD_E_ARG;
+    return decode_scans_impl(n_images, frames, scans, n_scans, files, file_lens, rgb_out, row_strides, nullptr, 0, status, device);
 }

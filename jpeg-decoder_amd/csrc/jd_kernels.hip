@@ -7,7 +7,7 @@
 //                                          1156-1169, 1252-1316)
 //       k1_dc_scan                         DC-prediction prefix scan as its own pass (images whose components all
 //                                          share one table pair: the block-in-MCU phase cannot self-synchronise)
-//   P   kp_scan                            progressive (SOF2) scans, one lane per scan (main.go:241-428)
+//   P   kp_scan                            progressive (SOF2) scans, one wave per scan (main.go:241-428)
 //   K2  k2_mcu_lanes                       dequantise + de-zigzag + fp64 truncating IDCT + chroma spread +
 //                                          float32 YCbCr->RGB (main.go:638-666, 454-606, 710-747, 669-707;
 //                                          zmap/map.go:3-68)
@@ -994,19 +994,28 @@ __global__ __launch_bounds__(1024) void k1_dc_scan(JdKernelArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Progressive (SOF2) scans, SURVEY row N4: decodeBandCoeffecients' SOF2 branch (main.go:241-428) under decodeHuffmanData's
 // block walk (main.go:749-816).  A progressive scan has no restart structure the reference acts on and every scan refines
-// what earlier scans of the same band left, so the unit of parallel work is the SCAN: one lane per scan, scans that do not
+// what earlier scans of the same band left, so the unit of parallel work is the SCAN: one wave per scan, scans that do not
 // depend on each other (different components or disjoint bands) in one launch, dependent ones in later launches (the
 // host orders them in levels).  Coefficients accumulate in the same int16 buffer, same layout, as the baseline writer's;
 // K2 then runs unchanged.
+//
+// Inside a scan the symbols are a serial chain: lane 0 walks it, out of LDS only -- the scan's symbol tables and a 2 KiB
+// window of its bytes are staged there by all 64 lanes.  What does not depend on the chain runs wave-wide:
+//   * DC refinement (main.go:312-320) is one bit per block at a known position: 64 blocks per step, one per lane;
+//   * AC refinement (main.go:321-427) reads a correction bit for every coefficient that is already non-zero: the 64 lanes
+//     hold the block (one coefficient each, the next block's already loading), a wave ballot hands lane 0 the non-zero
+//     mask, lane 0 turns symbols and correction bits into three 64-bit masks (corrected / new / new-and-negative), and the
+//     lanes apply them to their own coefficient and store it if it changed.
 // ------------------------------------------------------------------------------------------------
-struct PBits {                 // MSB-first reader over an unstuffed scan (BitReader, main.go:1252-1295)
-    const uint32_t* p;         // stream, read as aligned big-endian dwords (zero padded behind the data)
-    uint32_t ndw, next;        // dwords available / next dword to load
+#define JD_P_RING_DW 512u                                       // stream window in LDS: two halves of 1 KiB
+struct PBits {                 // MSB-first reader (BitReader, main.go:1252-1295) over the LDS window; lane 0 only
+    uint32_t ring;             // byte offset of the window in dyn_lds
+    uint32_t next;             // next stream dword to take (absolute index; the window holds the JD_P_RING_DW around it)
     uint64_t acc;              // unread bits, left aligned
     int n;                     // how many
     uint32_t used;             // bits consumed
     __device__ __forceinline__ void fill() {
-        if (n <= 32) { const uint32_t d = next < ndw ? be32(p[next]) : 0u; next++; acc |= (uint64_t)d << (32 - n); n += 32; }
+        if (n <= 32) { const uint32_t d = lds_u32(ring + ((next & (JD_P_RING_DW - 1u)) << 2)); next++; acc |= (uint64_t)d << (32 - n); n += 32; }
     }
     __device__ __forceinline__ uint32_t get(uint32_t k) {    // readBits (k <= 16; 0 bits = 0)
         fill();
@@ -1015,11 +1024,11 @@ struct PBits {                 // MSB-first reader over an unstuffed scan (BitRe
         return v;
     }
 };
-// scanSymbol (main.go:1297-1316) by table lookup; returns 0x100 for a code the table does not have
-__device__ __forceinline__ uint32_t pscan_symbol(PBits& br, const uint32_t* __restrict__ lut) {
+// scanSymbol (main.go:1297-1316) by table lookup (table in LDS); returns 0x100 for a code the table does not have
+__device__ __forceinline__ uint32_t pscan_symbol(PBits& br, uint32_t lut) {
     br.fill();
-    uint32_t e = lut[(uint32_t)(br.acc >> (64 - JD_LUT_BITS))];
-    if (e & 0x80000000u) e = lut[(e & 0x7FFFFFFFu) + ((uint32_t)(br.acc >> (64 - JD_LUT_BITS - 6)) & 63u)];
+    uint32_t e = lds_u32(lut + ((uint32_t)(br.acc >> (64 - JD_LUT_BITS)) << 2));
+    if (e & 0x80000000u) e = lds_u32(lut + (((e & 0x7FFFFFFFu) + ((uint32_t)(br.acc >> (64 - JD_LUT_BITS - 6)) & 63u)) << 2));
     if (e == 0) return 0x100u;
     const uint32_t len = e >> 8;
     br.acc <<= len; br.n -= (int)len; br.used += len;
@@ -1029,114 +1038,205 @@ __device__ __forceinline__ int pextend(uint32_t v, uint32_t len) {   // main.go:
     return (len != 0 && v < (1u << (len - 1))) ? (int)v - (int)((1u << len) - 1u) : (int)v;
 }
 
-// one block of one scan: `blk` = the block's 64 coefficients in zig-zag order (cmap[index] in the Go code is the natural
-// position of zig-zag index `index`; this buffer is kept in zig-zag order, so index addresses it directly)
-__device__ __forceinline__ uint32_t pscan_block(const JdPScan& sc, PBits& br, const uint32_t* dcl, const uint32_t* acl, int& prev_dc,
-                                                uint32_t& skips, int16_t* __restrict__ blk) {
-    const uint32_t ss = sc.ss, se = sc.se, al = sc.al;
-    uint32_t err = 0;
-    auto put = [&](uint32_t i, int v) { if (v != (int)(short)v) err |= JD_ST_COEF; blk[i] = (int16_t)v; };
-    if (ss == 0 && sc.ah == 0) {                               // DC first visit, main.go:243-253
-        const uint32_t sym = pscan_symbol(br, dcl);
-        if (sym > 16u) return JD_ST_HUFF;
-        const int v = pextend(br.get(sym), sym) + prev_dc;
-        prev_dc = v;
-        put(0, v << al);
-    } else if (ss != 0 && sc.ah == 0) {                        // AC first visit, main.go:254-311
-        if (skips > 0) { skips -= 1; return 0; }
-        uint32_t index = ss;
-        while (index <= se) {
-            const uint32_t sym = pscan_symbol(br, acl);
-            if (sym > 0xFFu) return JD_ST_HUFF;
-            if (sym == 0xF0u) {                                // sixteen zeros (already zero: first visit)
-                if (index + 16u > 64u) return JD_ST_COEF;
-                index += 16u;
-            } else {
-                const uint32_t zeros = sym >> 4, len = sym & 15u;
-                if (len != 0) {
-                    index += zeros;
-                    if (index > 63u) return JD_ST_COEF;
-                    put(index, pextend(br.get(len), len) << al);
-                    index++;
-                } else {                                       // EOBn: this block is done, the next `skips` blocks too
-                    skips = ((1u << zeros) - 1u) + br.get(zeros);
-                    return err;
-                }
-            }
-        }
-    } else if (ss == 0) {                                      // DC refinement, main.go:312-320
-        blk[0] = (int16_t)(blk[0] | (int)(br.get(1) << al));
-    } else {                                                   // AC refinement, main.go:321-427
-        const int positive = 1 << al, negative = -(1 << al);
-        auto refine = [&](uint32_t i) {                        // a correction bit for every coefficient that is already non-zero
-            const int cur = blk[i];
-            if (br.get(1)) put(i, cur >= 0 ? cur + positive : cur + negative);
-        };
-        uint32_t index = ss;
-        if (skips == 0) {
-            while (index <= se) {
-                const uint32_t sym = pscan_symbol(br, acl);
-                if (sym > 0xFFu) return JD_ST_HUFF;
-                uint32_t zeroes = sym >> 4;
-                const uint32_t len = sym & 15u;
-                int coeff = 0;
-                if (len != 0) {
-                    if (len != 1) return JD_ST_COEF;
-                    coeff = br.get(1) ? positive : negative;
-                }
-                if (len == 0 && sym != 0xF0u) { skips = (1u << zeroes) + br.get(zeroes); break; }
-                for (;;) {                                     // main.go:369-394
-                    if (index > 63u) return JD_ST_COEF;
-                    if (blk[index] != 0) refine(index);
-                    else { if (zeroes == 0) break; zeroes -= 1; }
-                    index += 1;
-                }
-                blk[index] = (int16_t)coeff;
-                index += 1;
-            }
-        }
-        if (skips > 0) {
-            for (; index <= se; index++) if (blk[index] != 0) refine(index);
-            skips -= 1;
-        }
-    }
-    return err;
-}
-
 __global__ __launch_bounds__(64) void kp_scan(JdKernelArgs a, const JdPScan* __restrict__ scans, const uint32_t* __restrict__ list,
-                                               int n, const uint8_t* __restrict__ pstream, const uint32_t* __restrict__ plut) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= n) return;
-    const JdPScan sc = scans[list[t]];
+                                               const uint8_t* __restrict__ pstream, const uint32_t* __restrict__ plut) {
+    const JdPScan sc = scans[list[blockIdx.x]];
     const JdImg& im = a.imgs[sc.img];
-    PBits br;
-    br.p = reinterpret_cast<const uint32_t*>(pstream + sc.stream_off); br.ndw = (sc.stream_len + 3u) >> 2; br.next = 0;
-    br.acc = 0; br.n = 0; br.used = 0;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t* __restrict__ stream = reinterpret_cast<const uint32_t*>(pstream + sc.stream_off);
+    const uint32_t ndw = (sc.stream_len + 3u) >> 2;
     int16_t* const cf = a.coef + im.coef_off;
     const uint32_t hs = im.hs, vs = im.vs, nl = hs * vs;
+    const uint32_t hsh = hs - 1u, vsh = vs - 1u;                // sampling factors are 1 or 2: divide and modulo by shift and mask
     const uint32_t bw = (im.width + 7u) >> 3, bh = (im.height + 7u) >> 3;          // main.go:160-161
     // decodeHuffmanData, main.go:753-770: a scan of the first component alone walks its blocks in raster order, anything
     // else walks the MCU grid
     const bool lum_only = sc.ncomp == 1 && sc.comp[0] == 0;
     const uint32_t xstep = lum_only ? 1u : hs, ystep = lum_only ? 1u : vs;
-    int prev_dc[3] = { 0, 0, 0 };
-    uint32_t skips = 0, err = 0;
-    for (uint32_t y = 0; y < bh && !err; y += ystep)
-        for (uint32_t x = 0; x < bw && !err; x += xstep)
-            for (uint32_t k = 0; k < sc.ncomp && !err; k++) {
-                const uint32_t cp = sc.comp[k];
-                const uint32_t* dcl = plut + (sc.dc_lut[k] == 0xFFFFFFFFu ? 0u : sc.dc_lut[k]);
-                const uint32_t* acl = plut + (sc.ac_lut[k] == 0xFFFFFFFFu ? 0u : sc.ac_lut[k]);
-                const uint32_t umax = (lum_only || cp) ? 1u : vs, vmax = (lum_only || cp) ? 1u : hs;
-                for (uint32_t u = 0; u < umax && !err; u++)
-                    for (uint32_t v = 0; v < vmax && !err; v++) {
-                        const uint32_t bx = x + v, by = y + u;
-                        const uint32_t mcu = (by / vs) * im.mcux + bx / hs;
-                        const uint32_t b = cp ? nl + cp - 1u : (by % vs) * hs + bx % hs;
-                        err |= pscan_block(sc, br, dcl, acl, prev_dc[cp], skips, cf + ((uint64_t)mcu * im.bpm + b) * 64u);
-                    }
+    const uint32_t ss = sc.ss, se = sc.se, al = sc.al;
+    uint32_t err = 0;
+
+    // ---- DC refinement: block n of the scan takes bit n; 64 blocks per step ----------------------------------
+    if (ss == 0 && sc.ah != 0) {
+        uint32_t n = 0;
+        for (uint32_t y = 0; y < bh; y += ystep)
+            for (uint32_t x = 0; x < bw; x += xstep)
+                for (uint32_t k = 0; k < sc.ncomp; k++) {
+                    const uint32_t cp = k == 0 ? sc.comp[0] : (k == 1 ? sc.comp[1] : sc.comp[2]);   // (no indexed access: it would live in scratch memory)
+                    const uint32_t umax = (lum_only || cp) ? 1u : vs, vmax = (lum_only || cp) ? 1u : hs;
+                    for (uint32_t u = 0; u < umax; u++)
+                        for (uint32_t v = 0; v < vmax; v++, n++) {
+                            if ((n & 63u) != lane) continue;
+                            const uint32_t bx = x + v, by = y + u;
+                            const uint32_t mcu = (by >> vsh) * im.mcux + (bx >> hsh);
+                            const uint32_t b = cp ? nl + cp - 1u : (by & vsh) * hs + (bx & hsh);
+                            const uint32_t d = (n >> 5) < ndw ? be32(stream[n >> 5]) : 0u;
+                            int16_t* p = cf + ((uint64_t)mcu * im.bpm + b) * 64u;
+                            *p = (int16_t)(*p | (int)(((d >> (31u - (n & 31u))) & 1u) << al));
+                        }
+                }
+        if (lane == 0 && n > sc.stream_len * 8u) atomicOr(&a.status[sc.img], (uint32_t)JD_ST_TRUNC);   // readBit -1 (main.go:1273)
+        return;
+    }
+
+    // ---- everything else: a serial chain of symbols, walked by lane 0 out of LDS -----------------------------------
+    // (components, tables and predictors are kept in named scalars: an indexed array would live in scratch memory, and the
+    // symbol loop would pay a memory round trip per access)
+    const uint32_t ring = 0, lutA = JD_P_RING_DW * 4u;
+    const uint32_t lutB = lutA + sc.lut_len[0] * 4u, lutC = lutB + (sc.ncomp > 1 ? sc.lut_len[1] * 4u : 0u);
+    auto stage_table = [&](uint32_t at, uint32_t off, uint32_t len) {
+        const uint32_t* src = plut + off;
+        for (uint32_t i = lane; i < len; i += 64u) *reinterpret_cast<uint32_t*>(dyn_lds + at + i * 4u) = src[i];
+    };
+    stage_table(lutA, sc.lut_off[0], sc.lut_len[0]);
+    if (sc.ncomp > 1) stage_table(lutB, sc.lut_off[1], sc.lut_len[1]);
+    if (sc.ncomp > 2) stage_table(lutC, sc.lut_off[2], sc.lut_len[2]);
+    const uint32_t cpA = sc.comp[0], cpB = sc.comp[1], cpC = sc.comp[2];
+    uint32_t filled = 0;                                       // stream dwords staged so far (wave-uniform)
+    auto top_up = [&](uint32_t next) {                         // keep >= 1 KiB staged ahead of the reader
+        while (filled < next + 256u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t i = filled + j * 64u + lane;
+                *reinterpret_cast<uint32_t*>(dyn_lds + ring + ((i & (JD_P_RING_DW - 1u)) << 2)) = i < ndw ? be32(stream[i]) : 0u;
             }
-    if (br.used > sc.stream_len * 8u) err |= JD_ST_TRUNC;                        // readBit -1 (main.go:1273)
+            filled += 256u;
+        }
+    };
+    top_up(0); top_up(256u);
+    wave_lds_order();
+    PBits br; br.ring = ring; br.next = 0; br.acc = 0; br.n = 0; br.used = 0;
+    int predA = 0, predB = 0, predC = 0;                        // prevDC of the scan's components (main.go:750)
+    uint32_t skips = 0;
+    const bool refine = ss != 0 && sc.ah != 0;
+    const int positive = 1 << al, negative = -(1 << al);
+    const uint32_t mcux = im.mcux, bpm = im.bpm;
+    auto block_ptr = [&](uint32_t cp, uint32_t bx, uint32_t by) {
+        const uint32_t mcu = (by >> vsh) * mcux + (bx >> hsh);
+        const uint32_t b = cp ? nl + cp - 1u : (by & vsh) * hs + (bx & hsh);
+        return cf + ((uint64_t)mcu * bpm + b) * 64u;
+    };
+    // AC scans hold one component (checked by the host): its blocks in walk order are (x, y) stepping as above
+    int cur = 0;                                               // refinement: this lane's coefficient of the current block
+    if (refine) cur = block_ptr(cpA, 0, 0)[lane];
+    for (uint32_t y = 0; y < bh && !err; y += ystep)
+        for (uint32_t x = 0; x < bw && !err; x += xstep) {
+            top_up(__builtin_amdgcn_readfirstlane(br.next));
+            wave_lds_order();
+            if (!refine) {
+                if (lane == 0) {
+                    if (ss == 0) {                             // DC first visit, main.go:243-253: the MCU's blocks of each component
+                        auto dc_first = [&](uint32_t cp, uint32_t lutk, int& pred) {
+                            const uint32_t umax = (lum_only || cp) ? 1u : vs, vmax = (lum_only || cp) ? 1u : hs;
+                            for (uint32_t u = 0; u < umax && !err; u++)
+                                for (uint32_t v = 0; v < vmax && !err; v++) {
+                                    const uint32_t sym = pscan_symbol(br, lutk);
+                                    if (sym > 16u) { err |= JD_ST_HUFF; break; }
+                                    const int val = pextend(br.get(sym), sym) + pred;
+                                    pred = val;
+                                    const int out = val << al;
+                                    if (out != (int)(short)out) err |= JD_ST_COEF;
+                                    block_ptr(cp, x + v, y + u)[0] = (int16_t)out;
+                                }
+                        };
+                        dc_first(cpA, lutA, predA);
+                        if (sc.ncomp > 1 && !err) dc_first(cpB, lutB, predB);
+                        if (sc.ncomp > 2 && !err) dc_first(cpC, lutC, predC);
+                    } else if (skips > 0) {                    // AC first visit, main.go:254-311: inside an end-of-band run
+                        skips -= 1;
+                    } else {
+                        int16_t* blk = block_ptr(cpA, x, y);
+                        uint32_t index = ss;
+                        while (index <= se) {
+                            const uint32_t sym = pscan_symbol(br, lutA);
+                            if (sym > 0xFFu) { err |= JD_ST_HUFF; break; }
+                            if (sym == 0xF0u) {                // sixteen zeros (already there: first visit)
+                                if (index + 16u > 64u) { err |= JD_ST_COEF; break; }
+                                index += 16u;
+                                continue;
+                            }
+                            const uint32_t zeros = sym >> 4, len = sym & 15u;
+                            if (len == 0) { skips = ((1u << zeros) - 1u) + br.get(zeros); break; }   // EOBn
+                            index += zeros;
+                            if (index > 63u) { err |= JD_ST_COEF; break; }
+                            const int out = pextend(br.get(len), len) << al;
+                            if (out != (int)(short)out) err |= JD_ST_COEF;
+                            blk[index] = (int16_t)out;
+                            index++;
+                        }
+                    }
+                }
+            } else {
+                // AC refinement, main.go:321-427.  Next block in walk order: its coefficients start loading now.
+                uint32_t nx = x + xstep, ny = y;
+                if (nx >= bw) { nx = 0; ny = y + ystep; }
+                int nxt = 0;
+                if (ny < bh) nxt = block_ptr(cpA, nx, ny)[lane];
+                const uint64_t nz = __builtin_amdgcn_ballot_w64(cur != 0);
+                uint64_t corr = 0, born = 0, bneg = 0;         // lane 0's verdict on the block
+                if (lane == 0) {
+                    // The Go loop looks at one coefficient at a time (main.go:369-394); on the non-zero mask the same walk
+                    // is arithmetic: the symbol's target is the (zeroes + 1)-th zero at or after `index`, and every non-zero
+                    // coefficient passed on the way takes one correction bit, in index order.
+                    auto take_bits = [&](uint64_t m) {          // a correction bit for each coefficient of m, ascending
+                        while (m) {
+                            uint32_t k = (uint32_t)__popcll(m); k = k > 16u ? 16u : k;
+                            const uint32_t v = br.get(k);      // first bit read = top bit of v = lowest index
+                            for (uint32_t j = 0; j < k; j++) {
+                                const uint64_t low = m & (0ull - m);
+                                if ((v >> (k - 1u - j)) & 1u) corr |= low;
+                                m ^= low;
+                            }
+                        }
+                    };
+                    uint32_t index = ss;
+                    if (skips == 0) {
+                        while (index <= se) {
+                            const uint32_t sym = pscan_symbol(br, lutA);
+                            if (sym > 0xFFu) { err |= JD_ST_HUFF; break; }
+                            const uint32_t zeroes = sym >> 4, len = sym & 15u;
+                            bool neg = false;
+                            if (len != 0) {
+                                if (len != 1) { err |= JD_ST_COEF; break; }
+                                neg = br.get(1) == 0;
+                            }
+                            if (len == 0 && sym != 0xF0u) { skips = (1u << zeroes) + br.get(zeroes); break; }
+                            const uint64_t from = ~0ull << index;
+                            uint64_t z = ~nz & from;           // zero coefficients at or after index
+                            for (uint32_t k = 0; k < zeroes && z; k++) z &= z - 1ull;
+                            if (!z) { err |= JD_ST_COEF; break; }                  // the run walks past coefficient 63
+                            const uint32_t p = (uint32_t)__builtin_ctzll(z);
+                            take_bits(nz & from & ((1ull << p) - 1ull));
+                            if (len != 0) { born |= 1ull << p; if (neg) bneg |= 1ull << p; }   // (ZRL: the sixteenth zero stays zero)
+                            index = p + 1u;
+                        }
+                    }
+                    if (skips > 0 && !err) {                   // inside an end-of-band run: the rest of the band is only corrected
+                        if (index <= se) take_bits(nz & (~0ull << index) & (se == 63u ? ~0ull : (1ull << (se + 1u)) - 1ull));
+                        skips -= 1;
+                    }
+                }
+                // (readfirstlane returns int: without the casts a set bit 31 would sign-extend into the upper half)
+                auto lane0 = [](uint64_t m) {
+                    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+                };
+                const uint64_t c64 = lane0(corr), b64 = lane0(born), n64 = lane0(bneg);
+                int val = cur;
+                if ((c64 >> lane) & 1ull) val = cur >= 0 ? cur + positive : cur + negative;
+                if ((b64 >> lane) & 1ull) val = ((n64 >> lane) & 1ull) ? negative : positive;
+                if (val != cur) {
+                    if (val != (int)(short)val) err |= JD_ST_COEF;
+                    block_ptr(cpA, x, y)[lane] = (int16_t)val;
+                }
+                cur = nxt;
+            }
+            if (__builtin_amdgcn_ballot_w64(err != 0)) {        // an error anywhere in the wave ends the scan
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) err |= __shfl_xor(err, d, 64);
+            }
+        }
+    if (lane == 0 && br.used > sc.stream_len * 8u) err |= JD_ST_TRUNC;             // readBit -1 (main.go:1273)
     if (err) atomicOr(&a.status[sc.img], err);
 }
 
@@ -1458,9 +1558,9 @@ void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s) {
 }
 
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
-                      const uint32_t* d_plut, hipStream_t s) {
+                      const uint32_t* d_plut, uint32_t max_lut_bytes, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(kp_scan, dim3((n + 63) / 64), dim3(64), 0, s, a, d_scans, d_list, n, d_pstream, d_plut);
+    hipLaunchKernelGGL(kp_scan, dim3(n), dim3(64), JD_P_RING_DW * 4u + max_lut_bytes, s, a, d_scans, d_list, d_pstream, d_plut);
 }
 
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {

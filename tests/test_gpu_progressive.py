@@ -48,3 +48,24 @@ def test_progressive_errors():
     assert e.value.code in (-8, -9, -10)
     out = jd.decode_progressive(bytes(data))                                     # still fine afterwards
     assert np.array_equal(out, orclib.OracleImage(bytes(data)).rgb)
+
+
+def test_progressive_batch():
+    """jd_decode_scans_batch: files of different geometry and scan scripts in one call, one of them damaged: every good
+    image equals the oracle's pixels, the damaged one reports its own error."""
+    paths = REF_P + TWINS[:6] + REF_P[:2]
+    files = [open(p, "rb").read() for p in paths]
+    fr, scans, n = jd.parse_scans(files[1])
+    bad = bytearray(files[1])
+    s = scans[5]
+    for k in range(s.ecs_off + 100, s.ecs_off + 400):          # wreck a stretch of a refinement scan
+        if bad[k] != 0xFF and bad[k - 1] != 0xFF:
+            bad[k] ^= 0x5A
+            if bad[k] == 0xFF:
+                bad[k] = 0x7F
+    files.append(bytes(bad))
+    outs, status = jd.decode_progressive_batch(files)
+    for i, f in enumerate(files[:-1]):
+        assert status[i] == 0, (i, status[i])
+        assert np.array_equal(outs[i], orclib.OracleImage(f).rgb), paths[i]
+    assert status[-1] in (0, -8, -9, -10)                       # damaged data: an error, or garbage pixels, never a hang
