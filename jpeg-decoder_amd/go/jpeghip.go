@@ -134,3 +134,111 @@ func writeBitMapRGB(name string, rgb []byte, width, height int) {
 		os.Exit(1)
 	}
 }
+
+// ---- throughput form (SURVEY row N3): main's file loop (main.go:1509-1512) over pinned-I/O batches ----------------
+// A gpuSlot is one JD_BATCH_PINNED_IO batch: the library owns pinned staging for the entropy-coded bytes of all its
+// images and for all their RGB.  The host keeps two or three slots going: while one is on the device (H2D copy ->
+// kernels -> D2H copy, all asynchronous) it fills the next.  All memory behind these pointers is C memory, so Go may
+// keep them between calls.
+type gpuSlot struct {
+	b       *C.jd_batch
+	names   []string
+	frames  []C.jd_frame
+	pending bool
+}
+
+// newSlot plans a slot for images with these frames (same geometry and tables as the files that will be staged).
+func newSlot(frames []C.jd_frame, ecsCap int) *gpuSlot {
+	jdInit()
+	caps := make([]C.size_t, len(frames))
+	for i := range caps {
+		caps[i] = C.size_t(ecsCap)
+	}
+	s := &gpuSlot{frames: frames, names: make([]string, len(frames))}
+	if rc := C.jd_batch_create(0, C.int(len(frames)), &frames[0], &caps[0], C.JD_BATCH_PINNED_IO, &s.b); rc != 0 {
+		fmt.Printf("%s\n", C.GoString(C.jd_strerror(rc)))
+		os.Exit(1)
+	}
+	return s
+}
+
+// stage copies image i's raw (stuffed) entropy-coded segment into the slot's pinned staging.
+func (s *gpuSlot) stage(i int, name string, rawECS []byte) {
+	var dst *C.uint8_t
+	if rc := C.jd_batch_stage_reserve(s.b, C.int(i), C.size_t(len(rawECS)), &dst); rc != 0 {
+		fmt.Printf("%s\n", C.GoString(C.jd_strerror(rc)))
+		os.Exit(1)
+	}
+	copy(unsafe.Slice((*byte)(unsafe.Pointer(dst)), len(rawECS)), rawECS)
+	s.names[i] = name
+}
+
+func (s *gpuSlot) submit() {
+	if rc := C.jd_batch_submit(s.b, nil); rc != 0 {
+		fmt.Printf("%s\n", C.GoString(C.jd_strerror(rc)))
+		os.Exit(1)
+	}
+	s.pending = true
+}
+
+// finish waits for the slot and writes its BMPs straight from the pinned RGB staging.
+func (s *gpuSlot) finish() {
+	if !s.pending {
+		return
+	}
+	if rc := C.jd_batch_wait(s.b); rc != 0 {
+		fmt.Printf("%s\n", C.GoString(C.jd_strerror(rc)))
+		os.Exit(1)
+	}
+	for i := range s.frames {
+		var p *C.uint8_t
+		var stride C.size_t
+		C.jd_batch_host_rgb(s.b, C.int(i), &p, &stride)
+		w, h := int(s.frames[i].width), int(s.frames[i].height)
+		writeBitMapRGB(s.names[i], unsafe.Slice((*byte)(unsafe.Pointer(p)), w*h*3), w, h)
+	}
+	s.pending = false
+}
+
+// ---- progressive files (SURVEY row N4) ------------------------------------------------------------------------
+// decodeStartOfScan (main.go:942-1063) keeps parsing SOS / DHT / DRI between the scans of an SOF2 file; instead of
+// running decodeHuffmanData per scan (main.go:1032) it appends scanFromHeader(...) to a list, and at EOI
+// (main.go:1053) hands the list to decodeScansOnGPU.  `file` is the whole file in memory (os.ReadFile), off / length
+// locate the scan's raw entropy-coded bytes in it.
+func scanFromHeader(header *Header, off, length int) C.jd_scan {
+	var sc C.jd_scan
+	sc.progressive = 1
+	sc.ss = C.uint8_t(header.startOfSelection)
+	sc.se = C.uint8_t(header.endOfSelection)
+	sc.ah = C.uint8_t(header.successiveApproximationHigh)
+	sc.al = C.uint8_t(header.successiveApproximationLow)
+	sc.ecs_off = C.uint64_t(off)
+	sc.ecs_len = C.uint64_t(length)
+	n := 0
+	for i := range header.cComponents {
+		c := &header.cComponents[i]
+		if c.usedInScan {
+			sc.comp[n] = C.uint8_t(i)
+			sc.td[n] = C.uint8_t(c.dcHuffmanTableId)
+			sc.ta[n] = C.uint8_t(c.acHuffmanTableId)
+			n++
+		}
+	}
+	sc.ncomp = C.uint8_t(n)
+	f := frameFromHeader(header) // snapshot of header.huffmanTables as they stand at this scan
+	sc.huff = f.huff
+	return sc
+}
+
+func decodeScansOnGPU(header *Header, scans []C.jd_scan, file []byte) []byte {
+	jdInit()
+	f := frameFromHeader(header)
+	rgb := make([]byte, header.width*header.height*3)
+	rc := C.jd_decode_scans(&f, &scans[0], C.int(len(scans)), (*C.uint8_t)(unsafe.Pointer(&file[0])), C.size_t(len(file)),
+		(*C.uint8_t)(unsafe.Pointer(&rgb[0])), C.size_t(header.width*3), 0)
+	if rc != 0 {
+		fmt.Printf("%s\n", C.GoString(C.jd_strerror(rc)))
+		os.Exit(1)
+	}
+	return rgb
+}
