@@ -31,7 +31,7 @@ void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t w
 void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
-void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, const JdIdctConst& K, hipStream_t s);
+void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K, hipStream_t s);
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
                       const uint32_t* d_plut, uint32_t max_lut_bytes, hipStream_t s);
 int jdk_static_scratch(void** ptr, size_t* bytes);
@@ -277,6 +277,7 @@ struct jd_batch {
     uint32_t max_lut_bytes = 0, max_w_bytes = 0;
     uint32_t wg_k0 = 0, wg_iv = 0, wg_sync = 0, wg_wr = 0, wg_tile = 0;
     bool dirty = true, ran = false, any_uniform = false;
+    uint32_t k2_modes = 0;                                       // bit m: some image has sampling mode m (k2_mcu_lanes<m>)
     hipStream_t stream = nullptr, last_stream = nullptr;
     bool own_stream = false;
     JdIdctConst K;
@@ -372,7 +373,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
         if (b->wg_wr && b->any_uniform) jdk_launch_dc_scan(a, s);
         break;
     case ST_IDCT_COLOUR:
-        jdk_launch_idct_colour(a, b->d_pre_tile, b->wg_tile, b->K, s);
+        jdk_launch_idct_colour(a, b->d_pre_tile, b->wg_tile, b->k2_modes, b->K, s);
         break;
     }
     HIPCHK(hipGetLastError());
@@ -429,6 +430,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
         im.width = f.width; im.height = f.height; im.mcux = g.mcux; im.mcuy = g.mcuy; im.n_mcus = g.mcux * g.mcuy;
         im.hs = g.hs; im.vs = g.vs; im.ncomp = f.ncomp; im.bpm = g.bpm;
         im.restart_interval = f.restart_interval;
+        b->k2_modes |= 1u << (f.ncomp == 1 ? 0 : g.hs + 2 * g.vs - 2);
         im.n_intervals = f.restart_interval ? (im.n_mcus + f.restart_interval - 1) / f.restart_interval : 1;
         // table set: per component (td, ta); identical (class,id) pairs share one packed table
         std::string key;

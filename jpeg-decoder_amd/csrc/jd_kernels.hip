@@ -17,6 +17,7 @@
 // exclusive prefix of workgroups-per-image.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 #include "jd_internal.h"
 
@@ -1273,13 +1274,41 @@ __device__ __forceinline__ void idct_1d(const JdIdctConst& K, int x0, int x1, in
 
 // convertColorSpace, main.go:679-703: float32, constants 1.402/0.344/0.714/1.772, +128 last, clamp to
 // [0,255], truncate.  The four chroma products are shared by the pixels that read the same chroma sample.
-// v_cvt_pk_u8_f32 saturates to [0,255] (measured on gfx950: -5.5 -> 0, 300 -> 255, 1e9 -> 255) but rounds to
-// nearest even, so v_floor_f32 goes first: floor(v) is an exact integer, equal to trunc(v) wherever the
-// reference's clamp leaves v alone (v >= 0), and below 0 / above 255 both forms end at 0 / 255.  The result
-// lands in byte `sel` of the packed output dword.
-__device__ __forceinline__ uint32_t put_u8(float v, uint32_t sel, uint32_t old) {
-    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(v), sel, old);
+// v_cvt_pk_u8_f32 saturates to [0,255] (measured on gfx950: -5.5 -> 0, 300 -> 255, 1e9 -> 255) and rounds as
+// MODE.FP_ROUND says (measured: 2.9999998 -> 3 under round-to-nearest, -> 2 under round-toward-zero).  The 24
+// conversions of a pixel row therefore run between two s_setreg that switch the f32 rounding mode to
+// toward-zero and back: trunc(v) wherever the reference's clamp leaves v alone, 0 / 255 outside -- with no
+// v_floor_f32 in front.  Nothing else may execute in that window (f32 adds and multiplies round by the same
+// field): the conversions and both mode writes are volatile asm statements, which keep their order, and the
+// values they read come out of a volatile fence placed before the first mode write (k2_rtz_*).
+template <int BYTE>
+__device__ __forceinline__ void k2_put_byte(uint32_t (&d)[6], float v) {
+    if constexpr ((BYTE & 3) == 0) asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(d[BYTE >> 2]) : "v"(v));
+    else asm volatile("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(d[BYTE >> 2]) : "v"(v), "n"(BYTE & 3));
 }
+typedef float jd_f32x2 __attribute__((ext_vector_type(2)));
+// byte BYTE of a group of NK pixel pairs (6 * NK bytes of a pixel row, starting at byte BASE): pixel BYTE / 3,
+// channel BYTE % 3
+template <int BASE, int BYTE, int NK>
+__device__ __forceinline__ void k2_put_group_byte(uint32_t (&d)[6], const jd_f32x2 (&R)[NK], const jd_f32x2 (&G)[NK],
+                                                  const jd_f32x2 (&B)[NK]) {
+    constexpr int px = BYTE / 3, ch = BYTE % 3;
+    const jd_f32x2& t = ch == 0 ? R[px >> 1] : ch == 1 ? G[px >> 1] : B[px >> 1];
+    k2_put_byte<BASE + BYTE>(d, t[px & 1]);
+}
+// the group's conversions, ordered so that consecutive ones write different dwords (back-to-back asm statements on
+// one register make hipcc put a wait state between them)
+template <int BASE, int NK, int... I>
+__device__ __forceinline__ void k2_put_group(uint32_t (&d)[6], const jd_f32x2 (&R)[NK], const jd_f32x2 (&G)[NK],
+                                             const jd_f32x2 (&B)[NK], std::integer_sequence<int, I...>) {
+    constexpr int ND = NK * 6 / 4;                                 // dwords the group fills
+    (k2_put_group_byte<BASE, (I % ND) * 4 + I / ND, NK>(d, R, G, B), ...);
+}
+#ifndef JD_K2_WIN_PAIRS
+#define JD_K2_WIN_PAIRS 4                                          // pixel pairs per conversion window (2 or 4)
+#endif
+__device__ __forceinline__ void k2_rtz_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3"); }
+__device__ __forceinline__ void k2_rtz_off() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"); }
 
 // ---- K2, MCU-per-lane form -----------------------------------------------------------------------------
 // One lane owns one whole MCU, one wave owns 64 consecutive MCUs; waves never talk to each other: no LDS, no
@@ -1414,6 +1443,8 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
 #pragma unroll
         for (int r = 0; r < 4; r++) {                              // chroma row r serves pixel rows 2r, 2r+1
             float rc[4], gb[4], gr[4], bc[4];
+            // fence: the products below stay behind the previous row's k2_rtz_off
+            asm volatile("" : "+v"(cq[0][r * 2]), "+v"(cq[0][r * 2 + 1]), "+v"(cq[1][r * 2]), "+v"(cq[1][r * 2 + 1]));
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t cbw = cq[0][r * 2 + (k >> 1)], crw = cq[1][r * 2 + (k >> 1)];
@@ -1423,31 +1454,49 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 rc[k] = __fmul_rn(1.402f, cr); gb[k] = __fmul_rn(0.344f, cb); gr[k] = __fmul_rn(0.714f, cr);
                 bc[k] = __fmul_rn(1.772f, cb);
             }
+            // fence: the products exist before the first k2_rtz_on below (the scheduler would otherwise sink the ones
+            // only later pixels use into an earlier conversion window)
+            asm volatile("" : "+v"(rc[0]), "+v"(rc[1]), "+v"(rc[2]), "+v"(rc[3]), "+v"(gb[0]), "+v"(gb[1]), "+v"(gb[2]), "+v"(gb[3]));
+            asm volatile("" : "+v"(gr[0]), "+v"(gr[1]), "+v"(gr[2]), "+v"(gr[3]), "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int i = 2 * r + h;
                 const uint32_t Yp = Y0 + by * 8u + (uint32_t)i;
                 int ys[8];                                         // row i of the luma block, straight from the row pass
                 row_pass(i, ys);
-                uint32_t d[6] = { 0, 0, 0, 0, 0, 0 };
+                // the two pixels that share chroma sample k, as one packed-f32 pair: the same additions in the same
+                // order as main.go:679-703, two at a time
+                typedef jd_f32x2 f32x2;
+                // fence: the row's samples are final before any f32 arithmetic of this row (keeps that arithmetic
+                // behind the previous row's k2_rtz_off)
+                asm volatile("" : "+v"(ys[0]), "+v"(ys[1]), "+v"(ys[2]), "+v"(ys[3]), "+v"(ys[4]), "+v"(ys[5]), "+v"(ys[6]), "+v"(ys[7]));
+                uint32_t d[6];
+                auto window = [&](auto hh_c) {                     // JD_K2_WIN_PAIRS pixel pairs: 6 values each in flight
+                    constexpr int hh = decltype(hh_c)::value, NK = JD_K2_WIN_PAIRS;
+                    f32x2 R[NK], G[NK], B[NK];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // the two pixels that share chroma sample k, as one packed-f32 pair: the same additions in the same
-                    // order as main.go:679-703, two at a time
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 y = { (float)ys[2 * k], (float)ys[2 * k + 1] };
-                    const f32x2 off = { 128.0f, 128.0f };
-                    const f32x2 R = (y + f32x2{ rc[k], rc[k] }) + off;
-                    const f32x2 G = ((y - f32x2{ gb[k], gb[k] }) - f32x2{ gr[k], gr[k] }) + off;
-                    const f32x2 B = (y + f32x2{ bc[k], bc[k] }) + off;
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int j = 2 * k + u;
-                        d[(3 * j) >> 2] = put_u8(R[u], (3 * j) & 3, d[(3 * j) >> 2]);
-                        d[(3 * j + 1) >> 2] = put_u8(G[u], (3 * j + 1) & 3, d[(3 * j + 1) >> 2]);
-                        d[(3 * j + 2) >> 2] = put_u8(B[u], (3 * j + 2) & 3, d[(3 * j + 2) >> 2]);
+                    for (int kk = 0; kk < NK; kk++) {
+                        const int k = NK * hh + kk;
+                        const f32x2 y = { (float)ys[2 * k], (float)ys[2 * k + 1] };
+                        const f32x2 off = { 128.0f, 128.0f };
+                        R[kk] = (y + f32x2{ rc[k], rc[k] }) + off;
+                        G[kk] = ((y - f32x2{ gb[k], gb[k] }) - f32x2{ gr[k], gr[k] }) + off;
+                        B[kk] = (y + f32x2{ bc[k], bc[k] }) + off;
                     }
-                }
+                    // fence: the values exist before the rounding mode changes
+#pragma unroll
+                    for (int kk = 0; kk < NK; kk += 2)
+                        asm volatile("" : "+v"(R[kk]), "+v"(R[kk + 1]), "+v"(G[kk]), "+v"(G[kk + 1]), "+v"(B[kk]), "+v"(B[kk + 1]));
+                    k2_rtz_on();
+                    k2_put_group<hh * NK * 6, NK>(d, R, G, B, std::make_integer_sequence<int, NK * 6>{});
+                    k2_rtz_off();
+                };
+                window(std::integral_constant<int, 0>{});
+#if JD_K2_WIN_PAIRS == 2
+                // fence: the second half's arithmetic starts behind the first half's k2_rtz_off
+                asm volatile("" : "+v"(ys[4]), "+v"(ys[5]), "+v"(ys[6]), "+v"(ys[7]));
+                window(std::integral_constant<int, 1>{});
+#endif
                 if (Yp < H && pair) {
                     uint8_t* stage = dyn_lds + 8192u + (uint32_t)i * 1536u + lane * 24u;
                     if (bx == 0) {
@@ -1478,18 +1527,22 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     }
 }
 
+// One kernel per sampling mode (0: grey, 1: 1x1, 2: 2x1, 3: 1x2, 4: 2x2): compiled together the five bodies share one
+// register allocation and spill (55 VGPRs; 113 with a whole pixel row per conversion window), alone the 4:2:0 body
+// needs 216.  A launch covers the batch's whole tile grid; tiles of images in another mode leave at once, and the
+// launcher only starts the modes the batch holds (jd_batch: k2_modes).
+__device__ __forceinline__ uint32_t k2_mode_of(const JdImg& im) { return im.ncomp == 1 ? 0u : im.hs + 2u * im.vs - 2u; }
+template <int MODE>
 __global__ __launch_bounds__(64, 2) void k2_mcu_lanes(JdKernelArgs a, JdIdctConst K) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
+    if (k2_mode_of(im) != (uint32_t)MODE) return;                  // wave-uniform
     const uint32_t tile = blockIdx.x - a.prefix[img];
-    const uint32_t mode = im.ncomp == 1 ? 0u : im.hs + 2u * im.vs - 2u;   // 1: 1x1, 2: 2x1, 3: 1x2, 4: 2x2
-    switch (mode) {                                                // wave-uniform
-    case 0: k2m_body<1, 1, 1>(a, im, tile, K); break;
-    case 1: k2m_body<1, 1, 3>(a, im, tile, K); break;
-    case 2: k2m_body<2, 1, 3>(a, im, tile, K); break;
-    case 3: k2m_body<1, 2, 3>(a, im, tile, K); break;
-    default: k2m_body<2, 2, 3>(a, im, tile, K); break;
-    }
+    if constexpr (MODE == 0) k2m_body<1, 1, 1>(a, im, tile, K);
+    else if constexpr (MODE == 1) k2m_body<1, 1, 3>(a, im, tile, K);
+    else if constexpr (MODE == 2) k2m_body<2, 1, 3>(a, im, tile, K);
+    else if constexpr (MODE == 3) k2m_body<1, 2, 3>(a, im, tile, K);
+    else k2m_body<2, 2, 3>(a, im, tile, K);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1573,10 +1626,16 @@ void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, ui
     hipLaunchKernelGGL(k1_write_subseq, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
-void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, const JdIdctConst& K, hipStream_t s) {
-    if (!wgs) return;
+void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K,
+                            hipStream_t s) {
     JdKernelArgs x = a; x.prefix = d_prefix;
-    hipLaunchKernelGGL(k2_mcu_lanes, dim3(wgs), dim3(64), 8192 + 8 * 1536, s, x, K);
+    if (!wgs) return;
+    const uint32_t lds = 8192 + 8 * 1536;
+    if (modes & 1u) hipLaunchKernelGGL(k2_mcu_lanes<0>, dim3(wgs), dim3(64), lds, s, x, K);
+    if (modes & 2u) hipLaunchKernelGGL(k2_mcu_lanes<1>, dim3(wgs), dim3(64), lds, s, x, K);
+    if (modes & 4u) hipLaunchKernelGGL(k2_mcu_lanes<2>, dim3(wgs), dim3(64), lds, s, x, K);
+    if (modes & 8u) hipLaunchKernelGGL(k2_mcu_lanes<3>, dim3(wgs), dim3(64), lds, s, x, K);
+    if (modes & 16u) hipLaunchKernelGGL(k2_mcu_lanes<4>, dim3(wgs), dim3(64), lds, s, x, K);
 }
 
 }  // extern "C"
