@@ -25,11 +25,12 @@ static const size_t kWriterLutTwoPerCu = (160 * 1024 / 2 - JD_W_WAVES * JD_WAVE_
 
 extern "C" {
 void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t wgs, hipStream_t s);
-void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
+void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s);
 void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
                      int flag_slot, int warm_off, hipStream_t s);
 void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
-void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
+void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s);
+void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, int16_t* d_out, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K, hipStream_t s);
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
@@ -147,7 +148,7 @@ extern "C" const char* jd_strerror(int code) {
     case JD_E_MARKER: return "Invalid marker found in the bitsteam";
     case JD_E_RESTART: return "Error! restart markers do not match the restart interval";
     case JD_E_HUFFMAN: return "Error! invalid DC Symbols";
-    case JD_E_COEF: return "Error! run/size walks past coefficient 63, or a predicted DC leaves 16 bits";
+    case JD_E_COEF: return "Error! run/size walks past coefficient 63, or a coefficient leaves 16 bits (AC 63 in the byte form: 12 bits)";
     case JD_E_TRUNCATED: return "Error! EOF";
     case JD_E_SYNC: return "internal error: self-synchronising decode did not converge";
     case JD_E_NOT_INIT: return "jd_init has not been called or found no device";
@@ -277,7 +278,9 @@ struct jd_batch {
     uint32_t max_lut_bytes = 0, max_w_bytes = 0;
     uint32_t wg_k0 = 0, wg_iv = 0, wg_sync = 0, wg_wr = 0, wg_tile = 0;
     bool dirty = true, ran = false, any_uniform = false;
-    uint32_t k2_modes = 0;                                       // bit m: some image has sampling mode m (k2_mcu_lanes<m>)
+    uint32_t k2_modes = 0;                                       // bit 2m + f: some image has sampling mode m and coefficient form f
+    uint32_t coef_fmts = 0;                                      // bit 0: some image keeps int16 coefficients, bit 1: some use bytes
+    int coef_form = 0;                                           // JD_COEF_FORM: 0 = choose per image, 8 / 16 = force
     hipStream_t stream = nullptr, last_stream = nullptr;
     bool own_stream = false;
     JdIdctConst K;
@@ -295,6 +298,10 @@ struct jd_batch {
     int sync_fixups = 2;                      // fix-up launches enqueued blindly; jd_batch_wait adds more if the flag says so
     int sync_warm_off = 0;                    // debug knob (JD_DEBUG_SYNC_NO_WARM)
 };
+
+// internal jd_batch_create flag (not in jpeghip.h): every image keeps int16 coefficients -- the progressive scans refine
+// coefficients in place
+#define JD_BATCH_COEF16_ 0x100u
 
 namespace {
 
@@ -358,7 +365,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
         jdk_launch_k0(a, b->d_pre_k0, b->wg_k0, s);
         break;
     case ST_HUFF_DRI:
-        jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, s);
+        jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, b->coef_fmts, s);
         break;
     case ST_HUFF_SYNC:
         if (b->wg_sync) {
@@ -369,7 +376,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
         }
         break;
     case ST_HUFF_WRITE:
-        jdk_launch_write_subseq(a, b->d_pre_wr, b->wg_wr, b->max_w_bytes, s);
+        jdk_launch_write_subseq(a, b->d_pre_wr, b->wg_wr, b->max_w_bytes, b->coef_fmts, s);
         if (b->wg_wr && b->any_uniform) jdk_launch_dc_scan(a, s);
         break;
     case ST_IDCT_COLOUR:
@@ -415,6 +422,8 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     b->status.assign(n_images, 0);
     b->sync_fixups = std::min(std::max(env_int("JD_SYNC_FIXUPS", 2), 0), 60);
     b->sync_warm_off = env_int("JD_DEBUG_SYNC_NO_WARM", 0) ? 1 : 0;
+    b->coef_form = env_int("JD_COEF_FORM", 0);                    // 8 / 16: force the coefficient form (tests); else per image
+    if (b->coef_form != 8 && b->coef_form != 16) b->coef_form = 0;
     if (dev) { b->arena.base = dev->scratch; b->arena.cap = dev->scratch_bytes; }
 
     // ---- Huffman table sets, de-duplicated across the batch -----------------------------------------
@@ -430,16 +439,36 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
         im.width = f.width; im.height = f.height; im.mcux = g.mcux; im.mcuy = g.mcuy; im.n_mcus = g.mcux * g.mcuy;
         im.hs = g.hs; im.vs = g.vs; im.ncomp = f.ncomp; im.bpm = g.bpm;
         im.restart_interval = f.restart_interval;
-        b->k2_modes |= 1u << (f.ncomp == 1 ? 0 : g.hs + 2 * g.vs - 2);
         im.n_intervals = f.restart_interval ? (im.n_mcus + f.restart_interval - 1) / f.restart_interval : 1;
         // table set: per component (td, ta); identical (class,id) pairs share one packed table
         std::string key;
         std::vector<uint16_t> set, sset;                          // single-symbol tables / sync-pass twin (same layout)
         std::vector<uint32_t> wset;                               // writer tables (32-bit entries)
         std::map<int, uint32_t> placed, wplaced, splaced;         // class*4+id -> entry offset in set / wset / sset
+        // All components on one table pair (legal, rare): the entropy decoder's path through the stream does not depend
+        // on the block-in-MCU phase, so that phase never self-synchronises.  The no-DRI path then runs its sync pass
+        // without the phase and predicts DC in a pass of its own (k1_dc_scan).
         bool uniform = f.ncomp > 1;
-        for (int c = 0; c < f.ncomp; c++) {
+        for (int c = 0; c < f.ncomp; c++)
             if (f.comp[c].td != f.comp[0].td || f.comp[c].ta != f.comp[0].ta) uniform = false;
+        if (uniform && f.restart_interval == 0) { im.flags |= JD_IMG_UNIFORM_TABLES; b->any_uniform = true; }
+        // Coefficient form.  Bytes (low plane + marked wide blocks in the high plane, write_segments8) halve the traffic
+        // between the Huffman writer and K2, but a wide block (an AC coefficient outside int8, |AC 63| > 7) is decoded
+        // twice: images whose quantisers make that common keep int16 -- an AC coefficient needs |DCT| >= 128 * q to
+        // leave int8 and 8-bit samples cannot reach 1024, so q >= 3 everywhere makes wide blocks an edge-of-a-checkerboard
+        // event.  Uniform-table images keep int16 (k1_dc_scan rewrites DC in place), and so do progressive files
+        // (JD_BATCH_COEF16_: their scans refine coefficients in place).
+        bool bytes = !(im.flags & JD_IMG_UNIFORM_TABLES) && !(flags & JD_BATCH_COEF16_);
+        if (bytes && b->coef_form == 0) {
+            for (int c = 0; c < f.ncomp && bytes; c++)
+                for (int k = 1; k < 64; k++) if (f.qt[f.comp[c].tq][k] < 3) { bytes = false; break; }
+        } else if (b->coef_form == 16) bytes = false;
+        if (bytes) im.flags |= JD_IMG_COEF8;
+        b->coef_fmts |= bytes ? 2u : 1u;
+        b->k2_modes |= (bytes ? 2u : 1u) << (2 * (f.ncomp == 1 ? 0 : g.hs + 2 * g.vs - 2));
+        const unsigned unit = bytes ? 1u : 2u;
+        key.push_back((char)unit);
+        for (int c = 0; c < f.ncomp; c++) {
             for (int cls = 0; cls < 2; cls++) {
                 const int id = cls ? f.comp[c].ta : f.comp[c].td;
                 const jd_huff& h = f.huff[cls][id];
@@ -452,7 +481,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                     else jd_pack_lut_multi(h.bits, h.vals, h.nvals, JD_SLUT_BITS, sset);
                     it = placed.emplace(cls * 4 + id, off).first;
                     wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
-                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_WIDE : JD_W32_DC_BITS, wset)) { batch_release(b); return JD_E_TABLE; }
+                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_WIDE : JD_W32_DC_BITS, unit, wset)) { batch_release(b); return JD_E_TABLE; }
                     key.append((const char*)h.bits, 16); key.append((const char*)h.vals, h.nvals); key.push_back((char)(cls * 4 + id));
                 }
                 (cls ? im.ac_lut : im.dc_lut)[c] = it->second;
@@ -462,10 +491,6 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
             key.push_back((char)(0x40 | (f.comp[c].td << 2) | f.comp[c].ta));
             memcpy(im.q[c], f.qt[f.comp[c].tq], 64);
         }
-        // All components on one table pair (legal, rare): the entropy decoder's path through the stream does not depend
-        // on the block-in-MCU phase, so that phase never self-synchronises.  The no-DRI path then runs its sync pass
-        // without the phase and predicts DC in a pass of its own (k1_dc_scan).
-        if (uniform && f.restart_interval == 0) { im.flags |= JD_IMG_UNIFORM_TABLES; b->any_uniform = true; }
         while (set.size() % 8) set.push_back(0);
         while (sset.size() % 8) sset.push_back(0);
         im.w_ac_bits = JD_W32_AC_BITS_WIDE;
@@ -477,7 +502,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                     if (!wplaced.count(cls * 4 + id)) {
                         wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
                         const jd_huff& h = f.huff[cls][id];
-                        if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_NARROW : JD_W32_DC_BITS, wset)) { batch_release(b); return JD_E_TABLE; }
+                        if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_NARROW : JD_W32_DC_BITS, unit, wset)) { batch_release(b); return JD_E_TABLE; }
                     }
                     (cls ? im.wac : im.wdc)[c] = wplaced[cls * 4 + id];
                 }
@@ -654,7 +679,7 @@ int wait_on(jd_batch* b) {
         // status bits and everything downstream of the sync records are recomputed
         HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));
         jdk_launch_k0(a, b->d_pre_k0, b->wg_k0, s);             // restores K0's status bits (idempotent)
-        jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, s);
+        jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, b->coef_fmts, s);
         jdk_launch_sync_spine(a, s);
         int rc = enqueue_stage(b, ST_HUFF_WRITE, s); if (rc) return rc;
         rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
@@ -809,6 +834,16 @@ extern "C" int jd_batch_coefficients(jd_batch* b, int image, int16_t* out, size_
     const size_t n = (size_t)im.n_mcus * im.bpm * 64;
     if (cap < n) return JD_E_ARG;
     HIPCHK(hipSetDevice(b->device));
+    if (im.flags & JD_IMG_COEF8) {                                // byte form: expand on the device into a temporary
+        int16_t* tmp = nullptr;
+        HIPCHK(hipMalloc((void**)&tmp, n * sizeof(int16_t)));
+        jdk_launch_coef8_expand(kernel_args(b), image, im.n_mcus * im.bpm, tmp, b->stream);
+        hipError_t he = hipMemcpyAsync(out, tmp, n * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(b->stream);
+        (void)hipFree(tmp);
+        if (he != hipSuccess) { g_last_hip = (int)he; return JD_E_HIP; }
+        return JD_OK;
+    }
     HIPCHK(hipMemcpyAsync(out, b->d_coef + im.coef_off, n * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return JD_OK;
@@ -1115,7 +1150,7 @@ int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const
     // ---- device: a batch supplies geometry, quantisation tables, coefficient buffers and K2 ----
     jd_batch* b = nullptr;
     std::vector<size_t> caps(n_images, 16);
-    int rc = jd_batch_create(device, n_images, fr.data(), caps.data(), JD_BATCH_KEEP_COEF, &b);
+    int rc = jd_batch_create(device, n_images, fr.data(), caps.data(), JD_BATCH_KEEP_COEF | JD_BATCH_COEF16_, &b);
     if (rc) return rc;
     struct Guard { jd_batch* b; ~Guard() { batch_release(b); } } guard{ b };
     DevBuf d_stream, d_lut, d_scans, d_list;

@@ -27,6 +27,7 @@
 //   bit 31 = 0 : [4:0]   32 - (code length + magnitude bits): how far to shift the window right to bring the
 //                        magnitude bits down -- a shift uses only these five bits, so the entry is the operand
 //                [15:8]  byte advance inside the block: 2 * (run + 1); 32 for ZRL; 254 for EOB; 0 for DC
+//                        (tables of images in the byte form: run + 1; 16; 127; 0)
 //                [30:16] magnitude mask 2^size - 1
 //   bit 31 = 1 : [30:0] offset (in entries, from the table start) of the secondary table
 //   0          : no code starts with these bits (invalid)
@@ -36,6 +37,7 @@
 #define JD_W32_AC_BITS_WIDE 10
 #define JD_W32_AC_BITS_NARROW 9
 #define JD_W32_EOB_ADV 254u
+#define JD_W32_EOB_ADV8 127u        // byte form (write_segments8): the advance counts coefficients, not bytes
 
 // self-synchronising decode: bits per sub-sequence (one lane each)
 #ifndef JD_SUBSEQ_BITS
@@ -86,8 +88,10 @@ enum {
 
 enum {
     JD_IMG_UNSTUFFED_INPUT = 1u,   // K0 is skipped, host filled stream + interval table
-    JD_IMG_UNIFORM_TABLES = 2u     // every component uses the same DC and the same AC table: the sync pass ignores the
+    JD_IMG_UNIFORM_TABLES = 2u,    // every component uses the same DC and the same AC table: the sync pass ignores the
                                    // block-in-MCU phase, the writer stores DC differences, k1_dc_scan predicts
+    JD_IMG_COEF8 = 4u              // coefficients travel from the Huffman writer to K2 as bytes: a 64-byte block in the low
+                                   // plane, the rare wide block's high parts in the high plane (write_segments8)
 };
 
 struct JdImg {

@@ -378,6 +378,8 @@ __device__ __forceinline__ uint4 la_u4(uint32_t addr) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void la_st16(uint32_t addr, int v) { *(__attribute__((address_space(3))) int16_t*)(uintptr_t)addr = (int16_t)v; }
+__device__ __forceinline__ void la_st8(uint32_t addr, int v) { *(__attribute__((address_space(3))) int8_t*)(uintptr_t)addr = (int8_t)v; }
+__device__ __forceinline__ int la_i8(uint32_t addr) { return *(__attribute__((address_space(3))) const int8_t*)(uintptr_t)addr; }
 __device__ __forceinline__ void la_st4(uint32_t addr, uint4 v) {
     jd_u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     *(__attribute__((address_space(3))) jd_u32x4*)(uintptr_t)addr = t;
@@ -622,10 +624,267 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
     if (err) atomicOr(&a.status[img], err);
 }
 
+// ---- whole-block writer, byte form (images flagged JD_IMG_COEF8) ------------------------------------------------
+// Same walk as write_segments, but a coefficient is stored as ONE byte, so a lane's 64-byte slot holds a whole block: one
+// symbol loop per block instead of two half-block phases (a wave waits for its slowest lane once per block: 25 % over the
+// mean symbol count on the benchmark images instead of 37 %), one flush per block, half the coefficient bytes to HBM.
+// Block in the byte plane (64 B, zig-zag order):
+//   byte 0       DC, low 8 bits                    byte 63 [3:0]  DC, bits 11..8
+//   bytes 1..62  AC coefficients as int8           byte 63 [7:4]  AC coefficient 63 in -7 .. 7, or 8 = WIDE block
+// A block with an AC magnitude category >= 8 (|v| >= 128), |AC 63| > 7 or a predicted DC outside 12 bits (no 8-bit
+// encoder produces one) is WIDE: its lane decodes it once more, straight from the unstuffed stream in global memory, and
+// writes the block's 64 bytes of the HIGH plane (second half of the image's coefficient region): byte 0 = DC bits 15..8,
+// bytes 1..62 = (v - int8(v)) >> 8 modulo 256 (zero where the low byte says it all), byte 63 = AC 63's low byte -- whose bits 11..8
+// take the DC's place in byte 63 [3:0] of the low plane.  K2 reads the high plane only for blocks that carry the mark.
+// Limits (JD_ST_COEF beyond them, as the int16 form does at 16 bits): DC 16 bits, AC 1..62 16 bits, AC 63 12 bits.
+// (Images whose quantisers make wide blocks common keep the int16 form: jd_api.cpp picks the form per image.)
+// Lines: two consecutive blocks share a 128-byte line.  A lane whose first block has an odd index starts one step late
+// (skew), so that in every lane the block of an even step is the first half of a line: even steps pick up and hold,
+// odd steps pick up and store the line; a half whose partner belongs to another segment goes out as 64 bytes.
+template <bool NT>
+__device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
+                                                const Segment& sg, uint32_t slen, uint32_t err) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lbase = lds_abs_base();
+    const uint32_t wbase = lbase + lut_bytes + wv * JD_WAVE_LDS;
+    const uint32_t slot_b = wbase + lane * 64u;
+    const uint32_t ring_b = wbase + 4096u + lane * 64u;
+    uint32_t dump_b = wbase + 8192u;
+    uint32_t four = 4u;
+    asm volatile("" : "+v"(dump_b), "+v"(four));
+    const uint32_t rot = (lane & 3u) << 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) la_st4(slot_b + i * 16, make_uint4(0, 0, 0, 0));
+    const uint32_t bpm = im.bpm, nl = im.hs * im.vs;
+    const uint32_t ac_bits = __builtin_amdgcn_readfirstlane(im.w_ac_bits);
+    const uint32_t dc0 = lbase + im.wdc[0] * 4u, dc1 = lbase + im.wdc[1] * 4u, dc2 = lbase + im.wdc[2] * 4u;
+    const uint32_t ac0 = lbase + im.wac[0] * 4u, ac1 = lbase + im.wac[1] * 4u, ac2 = lbase + im.wac[2] * 4u;
+
+    // ---- prime the ring (as write_segments) -------------------------------------------------------------------
+    const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
+    const uint32_t qmax = (JD_STREAM_FRONT + slen + JD_STREAM_TAIL) / 16u - 1u;
+    const uint32_t o0 = ((sg.start_bit - 1u) & 31u) + 1u;
+    const uint32_t g = ((sg.start_bit + 32u - o0) >> 5) + 3u;
+    const uint32_t qbase = (g >> 2) < qmax ? (g >> 2) : qmax;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint4 v = Q[qbase + k < qmax ? qbase + k : qmax];
+        la_st4(ring_b | ((k * 16u + rot) & 63u), be32x4(v));
+    }
+    uint32_t wqb = 64u + rot;
+    uint32_t rpb = (g & 3u) * 4u + rot;
+    wave_lds_order();
+    auto ring_at = [&](uint32_t xb) { return la_u32(ring_b | (xb & 63u)); };
+    uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 4), nxt = ring_at(rpb + 8);
+    rpb += 12;
+    uint32_t sh = 32u - o0;
+    uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;
+    uint32_t npend = 0;
+
+    int p0 = sg.p0, p1 = sg.p1, p2 = sg.p2;
+    uint32_t c = sg.nblk ? sg.blk0 % bpm : 0u;
+    uint32_t bad = 0;
+    // steps: this lane decodes block (st - skew) of its segment at step st, for st in [s_lo, s_hi)
+    const uint32_t s_lo = sg.nblk ? (sg.blk0 & 1u) : 0u, s_hi = s_lo + sg.nblk;
+    uint32_t nsteps = s_hi;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nsteps, d, 64); nsteps = t > nsteps ? t : nsteps; }
+    nsteps = (nsteps + 1u) & ~1u;                                          // a line is closed on an odd step
+    const uint32_t nblocks = im.n_mcus * bpm;
+    uint8_t* const lo_plane = reinterpret_cast<uint8_t*>(a.coef + im.coef_off);
+    typedef __attribute__((address_space(1))) uint8_t g_u8;
+    g_u8* const hi_plane = (g_u8*)(lo_plane + (uint64_t)nblocks * 64u);
+
+    // flush plan: in pass q lanes 8t'..8t'+7 move the line of lane t = 8q + (lane >> 3); lanes with bit 2 clear hold the
+    // four pieces of the even step's block, the others take the odd step's, then all eight store (those whose block exists)
+    const uint32_t part = lane & 3u, f_hi = (lane >> 2) & 1u;
+    const uint32_t base_blk = sg.blk0 - s_lo;                             // block index at step 0 (even)
+    uint32_t blk_first = sg.nblk ? base_blk : 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(blk_first, d, 64); blk_first = t < blk_first ? t : blk_first; }
+    blk_first = __builtin_amdgcn_readfirstlane(blk_first == 0xFFFFFFFFu ? 0u : blk_first);
+    uint8_t* const wave_dst = lo_plane + (uint64_t)blk_first * 64u;
+    uint32_t f_lo[8], f_end[8], f_off[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+        const uint32_t t = q * 8u + (lane >> 3);
+        const uint32_t tl = __shfl(s_lo, t, 64), th = __shfl(s_hi, t, 64), tb = __shfl(base_blk, t, 64);
+        // this lane's piece of line (st - 1, st) comes from step st - 1 + f_hi: fold that into the bounds
+        f_lo[q] = tl + 1u - f_hi; f_end[q] = th + 1u - f_hi;
+        f_off[q] = th > tl ? (tb - blk_first) * 64u + (lane & 7u) * 16u : 0u;
+    }
+    const uint32_t f_src = wbase + (lane >> 3) * 64u + ((part ^ ((lane >> 3) & 3u)) << 4);   // + q * 512
+    uint4 f_hold[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) f_hold[q] = make_uint4(0, 0, 0, 0);
+
+    auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rot) >> 4); return q < qmax ? q : qmax; };
+    auto request = [&](bool want) {
+        const uint32_t used = (wqb >> 4) - (rpb >> 4);
+        const uint32_t freeq = 4u - used;
+        npend = want ? (freeq < 2u ? freeq : 2u) : 0u;
+        if (npend >= 1) pq0 = Q[quad_index(wqb)];
+        if (npend >= 2) pq1 = Q[quad_index(wqb + 16u)];
+    };
+    auto commit = [&]() {
+        if (npend >= 1) la_st4(ring_b | (wqb & 63u), be32x4(pq0));
+        if (npend >= 2) la_st4(ring_b | ((wqb + 16u) & 63u), be32x4(pq1));
+        wqb += npend * 16u; npend = 0;
+    };
+    auto top_up_now = [&]() {
+        if (rpb >= wqb) {
+            commit();
+            if (rpb >= wqb) {
+                const uint4 v = Q[quad_index(wqb)];
+                la_st4(ring_b | (wqb & 63u), be32x4(v));
+                wqb += 16u;
+            }
+        }
+        wave_lds_order();
+    };
+    auto advance = [&](uint32_t e, uint32_t cand) {
+        const uint32_t t = sh + (e & 31u);
+        const bool r = t < 32u;
+        sh = t & 31u;
+        w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
+        rpb += r ? four : 0u;
+    };
+    auto flush = [&](uint32_t st) {
+        const uint32_t odd = st & 1u;                                     // wave-uniform
+        if (f_hi == odd) {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                f_hold[q] = la_u4(f_src + q * 512u);
+                la_st4(f_src + q * 512u, make_uint4(0, 0, 0, 0));
+            }
+        }
+        if (odd) {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                if (st >= f_lo[q] && st < f_end[q]) {
+                    jd_u32x4 t; t.x = f_hold[q].x; t.y = f_hold[q].y; t.z = f_hold[q].z; t.w = f_hold[q].w;
+                    jd_u32x4* at = reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)(st - 1u) * 64u);
+                    if (NT) __builtin_nontemporal_store(t, at); else *at = t;
+                }
+            }
+        }
+    };
+    // A wide block, once more: symbols straight from global memory (the ring has moved on), high-plane bytes out.
+    auto wide_block = [&](uint32_t pos, uint32_t dcb, uint32_t acb, uint32_t blk, int pred) -> uint32_t {
+        const uint32_t* S = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
+        const uint32_t imax = (slen + JD_STREAM_TAIL) / 4u - 2u;
+        auto window = [&](uint32_t p) {
+            uint32_t i = p >> 5; i = i < imax ? i : imax;
+            const uint32_t d0 = be32(S[i]), d1 = be32(S[i + 1]);
+            return (p & 31u) ? __builtin_amdgcn_alignbit(d0, d1, 32u - (p & 31u)) : d0;
+        };
+        g_u8* hib = hi_plane + (uint64_t)blk * 64u;
+        typedef __attribute__((address_space(1))) jd_u32x4 g_u4;
+        jd_u32x4 z; z.x = z.y = z.z = z.w = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) ((g_u4*)hib)[i] = z;
+        hib[0] = (uint8_t)((uint32_t)pred >> 8);
+        uint32_t junk = 0, ac63_hi = 0;
+        uint32_t e = w32_lookup(dcb, window(pos), JD_W32_DC_BITS, junk);
+        pos += 32u - (e & 31u);
+        uint32_t k = 0;
+        while (k < 63u) {
+            const uint32_t win = window(pos);
+            e = w32_lookup(acb, win, ac_bits, junk);
+            const int v = w32_value(win, e);
+            pos += 32u - (e & 31u);
+            k += (e >> 8) & 255u;
+            if (k > 63u) break;
+            if (k == 63u) {
+                hib[63] = (uint8_t)v; ac63_hi = ((uint32_t)v >> 8) & 15u;
+                if (v != ((v << 20) >> 20)) err |= JD_ST_COEF;
+            } else {
+                const int hc = (v - (int)(int8_t)v) >> 8;
+                if (hc != 0) hib[k] = (uint8_t)hc;
+            }
+        }
+        return ac63_hi;
+    };
+
+    // `o` = zig-zag index of the coefficient the last symbol produced.  A symbol adds its advance (run + 1; 127 for EOB)
+    // and stores its value's low byte at the new index when that is inside the block (else to the dump byte).
+    const uint32_t idle = 1u << 20;
+#pragma unroll 1
+    for (uint32_t st = 0; st < nsteps; st++) {
+        const bool act = st >= s_lo && st < s_hi;
+        request(act);
+        wave_lds_order();
+        const uint32_t comp = c < nl ? 0u : c - nl + 1u;
+        const uint32_t dcb = sel3(comp, dc0, dc1, dc2);
+        const uint32_t acb = sel3(comp, ac0, ac1, ac2);
+        uint32_t o = idle, e = 0, wacc = 0, wacc_dc = 0, dchi = 0;
+        int dcv = 0;
+        const uint32_t rpb0 = rpb, sh0 = sh;                              // where this block starts (for wide_block)
+        if (act) {
+            if (__builtin_amdgcn_ballot_w64(rpb >= wqb)) top_up_now();
+            const uint32_t cand = ring_at(rpb);
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
+            e = w32_lookup(dcb, win, JD_W32_DC_BITS, bad);
+            const int diff = w32_value(win, e);
+            advance(e, cand);
+            const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
+            p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
+            if (pred != (int)(short)pred) err |= JD_ST_COEF;             // as the int16 form
+            if (pred != ((pred << 20) >> 20)) wacc_dc = 1u << 23;        // outside 12 bits: a wide block
+            la_st8(slot_b + rot, pred);
+            dchi = ((uint32_t)pred >> 8) & 15u;
+            dcv = pred;
+            o = 0;
+        }
+        while (o < 63u) {                                                 // divergent loop: finished lanes drop out
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
+            const uint32_t cand = ring_at(rpb);
+            const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
+            e = w32_lookup(acb, win, ac_bits, bad);
+            const int v = w32_value(win, e);
+            advance(e, cand);
+            o += (e >> 8) & 255u;
+            const uint32_t at = o < 64u ? slot_b + (o ^ rot) : dump_b;
+            la_st8(at, v);
+            wacc |= e;
+        }
+        if (act) {
+            // a block ends at index 63 exactly or by EOB (>= 127); in between = a run that walked past coefficient 63
+            if (o > 63u && o < 127u) err |= JD_ST_COEF;
+            wave_lds_order();
+            const int b63 = la_i8(slot_b + (63u ^ rot));
+            const bool wide = ((wacc | wacc_dc) & (1u << 23)) != 0 || (uint32_t)(b63 + 7) > 14u;
+            uint32_t low4 = dchi;
+            if (__builtin_expect(wide, 0)) {
+                const uint32_t rp = (rpb0 - rot) >> 2;
+                const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - sh0);
+                low4 = wide_block(pos, dcb, acb, base_blk + st, dcv);
+            }
+            la_st8(slot_b + (63u ^ rot), (int)((wide ? 0x80u : ((uint32_t)b63 << 4)) | low4));
+        }
+        commit();
+        wave_lds_order();
+        flush(st);
+        wave_lds_order();
+        if (act) c = (c + 1u == bpm) ? 0u : c + 1u;
+    }
+    if (sg.nblk) {
+        if (bad) err |= JD_ST_HUFF;
+        const uint32_t rp = (rpb - rot) >> 2;
+        const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - sh);
+        if (pos > sg.end_bit) err |= JD_ST_TRUNC;
+    }
+    if (err) atomicOr(&a.status[img], err);
+}
+
 // ---- restart-interval path: segment = restart interval ------------------------------------------------
-__global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
+// C8: the launch serves the images whose coefficients are stored in the byte form (JD_IMG_COEF8); the other launch the rest
+template <bool C8>
+__global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1_write_intervals(JdKernelArgs a, uint32_t lut_bytes) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
+    if (((im.flags & JD_IMG_COEF8) != 0) != C8) return;         // workgroup-uniform
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
     const uint32_t ri = im.restart_interval;
     const uint32_t iv = (blockIdx.x - a.prefix[img]) * (64u * JD_W_WAVES) + threadIdx.x;
@@ -640,7 +899,8 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_intervals(JdKernelAr
             sg.start_bit = b0 * 8u; sg.end_bit = b1 * 8u; sg.nblk = nm * im.bpm; sg.blk0 = iv * ri * im.bpm;
         }
     }
-    write_segments<true>(a, im, img, lut_bytes, sg, slen, err);
+    if constexpr (C8) write_segments8<true>(a, im, img, lut_bytes, sg, slen, err);
+    else write_segments<true>(a, im, img, lut_bytes, sg, slen, err);
 }
 
 // ---- no-DRI path, pass 1: self-synchronising sub-sequences --------------------------------------------
@@ -929,9 +1189,11 @@ __global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
 
 // ---- no-DRI path, pass 2: segment = the blocks that start inside one sub-sequence ------------------------
 // Lane L of the image handles owned lane L % JD_SYNC_WG of sync workgroup L / JD_SYNC_WG.
-__global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs a, uint32_t lut_bytes) {
+template <bool C8>
+__global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1_write_subseq(JdKernelArgs a, uint32_t lut_bytes) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
+    if (((im.flags & JD_IMG_COEF8) != 0) != C8) return;         // workgroup-uniform
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
@@ -963,7 +1225,8 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1_write_subseq(JdKernelArgs 
         }
         if (!sg.nblk) { sg.start_bit = 0; sg.blk0 = 0; }
     }
-    write_segments<true>(a, im, img, lut_bytes, sg, slen, err, uniform);
+    if constexpr (C8) write_segments8<true>(a, im, img, lut_bytes, sg, slen, err);   // (uniform-table images keep int16)
+    else write_segments<true>(a, im, img, lut_bytes, sg, slen, err, uniform);
 }
 
 // ---- DC-prediction prefix scan as its own pass --------------------------------------------------------------
@@ -1317,14 +1580,20 @@ __device__ __forceinline__ void k2_rtz_off() { asm volatile("s_setreg_imm32_b32 
 // convert the 8 x 8 pixels against the chroma quadrant (PY>>1, PX>>1) and store 24-byte rows.  The block loop is
 // a real loop (the IDCT and colour code exist once); only the register shuffles that pick the chroma quadrant
 // are specialised per block.
-template <int HS, int VS, int NC>
+// C8: the image's coefficients are in the byte form (write_segments8): 64 bytes per block in the low plane, the high
+// plane only for blocks that carry the wide mark.
+template <int HS, int VS, int NC, bool C8>
 __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im, uint32_t tile, const JdIdctConst& K) {
     constexpr uint32_t NL = HS * VS, BPM = NL + NC - 1;
+    constexpr int NP = C8 ? 4 : 8;                                 // 16-byte pieces per block
     const uint32_t M = tile * 64u + (threadIdx.x & 63u);
     if (M >= im.n_mcus) return;
     const uint32_t my = M / im.mcux, mx = M - my * im.mcux;
     const uint32_t X0 = mx * 8u * HS, Y0 = my * 8u * VS;
-    const uint4* __restrict__ cbase = reinterpret_cast<const uint4*>(a.coef + im.coef_off + (uint64_t)M * BPM * 64u);
+    const uint8_t* const cplane = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off);
+    const uint4* __restrict__ cbase = reinterpret_cast<const uint4*>(cplane + (uint64_t)M * BPM * (NP * 16u));
+    typedef __attribute__((address_space(1))) const jd_u32x4 g_cu4;
+    g_cu4* const hbase = (g_cu4*)(cplane + ((uint64_t)im.n_mcus * BPM + (uint64_t)M * BPM) * 64u);   // C8: this MCU in the high plane
     const uint32_t rs = im.row_stride, W = im.width, H = im.height;
     // a copy (stores through it must not force reloads of `im`), in the GLOBAL address space: a generic-pointer
     // store could alias LDS, so hipcc would drain the LDS-DMA queue (and every earlier store) before each one
@@ -1345,9 +1614,9 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     const uint32_t lane = threadIdx.x & 63u;
     auto block_of = [&](uint32_t st) { return st < (uint32_t)(NC - 1) ? NL + st : st - (uint32_t)(NC - 1); };   // chroma first
     auto fetch = [&](uint32_t st) {
-        const uint4* src = cbase + block_of(st) * 8u;
+        const uint4* src = cbase + block_of(st) * (uint32_t)NP;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < NP; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
                                              (__attribute__((address_space(3))) void*)(dyn_lds + i * 1024),
                                              16, 0, 0);
@@ -1365,20 +1634,69 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
 #pragma unroll
             for (int i = 0; i < 16; i++) qw[i] = __builtin_amdgcn_readfirstlane(qp[i]);
         }
-        uint32_t cw[32];
+        uint32_t cw[NP * 4];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < NP; i++) {
             const uint4 v = *reinterpret_cast<const uint4*>(dyn_lds + i * 1024 + lane * 16u);
             cw[i * 4 + 0] = v.x; cw[i * 4 + 1] = v.y; cw[i * 4 + 2] = v.z; cw[i * 4 + 3] = v.w;
         }
         // the DMA of the next block reuses the buffer: the reads above must have returned first (LDS-DMA writes
         // arrive through the vector-memory path and are not ordered behind ds_read)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // byte form: a block marked wide (high nibble of byte 63 = 8) has its high parts in the high plane; they are
+        // fetched before the next block's DMA is queued behind them
+        uint32_t hw[C8 ? 16 : 1];
+        bool wflag = false, anyw = false;
+        if constexpr (C8) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) hw[i] = 0;
+            wflag = (cw[15] >> 28) == 8u;
+            anyw = __builtin_amdgcn_ballot_w64(wflag) != 0;    // wave-uniform, rare
+            if (anyw && wflag) {
+                g_cu4* hp = hbase + b * 4u;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const jd_u32x4 v = hp[i]; hw[i * 4] = v.x; hw[i * 4 + 1] = v.y; hw[i * 4 + 2] = v.z; hw[i * 4 + 3] = v.w; }
+            }
+        }
         if (st + 1u < BPM) fetch(st + 1u);
         // column pass; its outputs are truncated to int as the reference does (main.go:521-528).  (Keeping them in fp64
         // with trunc() would save the 64 conversions back, but 128 registers of intermediates spill: 162 VGPRs spilled.)
         int mid[64];
+        if constexpr (C8) {
+            // dequantise the whole block first (main.go:660-662), then run the column pass in place
+            auto qv_of = [&](int n) { return (int)((qw[n >> 2] >> ((n & 3) * 8)) & 0xFFu); };
+            auto lo8 = [&](int zi) { return (int)(int8_t)(cw[zi >> 2] >> ((zi & 3) * 8)); };
+            const int low4 = (int)(cw[15] << 4) >> 28;                  // byte 63 [3:0], sign-extended
+            const int dc = (int)((low4 << 8) | (int)(cw[0] & 0xFFu));
+            if (anyw) {
+                auto hi8 = [&](int zi) { return (int)(int8_t)(hw[zi >> 2] >> ((zi & 3) * 8)); };
+#pragma unroll
+                for (int n = 0; n < 64; n++) {
+                    const int zi = kZZ.n2z[n];
+                    int cv;
+                    if (zi == 0) cv = wflag ? (int)((hi8(0) << 8) | (int)(cw[0] & 0xFFu)) : dc;
+                    else if (zi == 63) cv = wflag ? (int)((low4 << 8) | (int)(hw[15] >> 24)) : ((int)cw[15] >> 28);
+                    else cv = (int)(short)(lo8(zi) + (hi8(zi) << 8));   // (the high part is modulo 256: 32767 = -1 + (-128 << 8))
+                    mid[n] = __mul24(cv, qv_of(n));
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 64; n++) {
+                    const int zi = kZZ.n2z[n];
+                    const int cv = zi == 0 ? dc : zi == 63 ? ((int)cw[15] >> 28) : lo8(zi);
+                    mid[n] = __mul24(cv, qv_of(n));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int o[8];
+                idct_1d(K, mid[0 * 8 + j], mid[1 * 8 + j], mid[2 * 8 + j], mid[3 * 8 + j], mid[4 * 8 + j], mid[5 * 8 + j],
+                        mid[6 * 8 + j], mid[7 * 8 + j], o);
+#pragma unroll
+                for (int r = 0; r < 8; r++) mid[r * 8 + j] = o[r];
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             int x[8];
@@ -1532,17 +1850,34 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
 // needs 216.  A launch covers the batch's whole tile grid; tiles of images in another mode leave at once, and the
 // launcher only starts the modes the batch holds (jd_batch: k2_modes).
 __device__ __forceinline__ uint32_t k2_mode_of(const JdImg& im) { return im.ncomp == 1 ? 0u : im.hs + 2u * im.vs - 2u; }
-template <int MODE>
+template <int MODE, bool C8>
 __global__ __launch_bounds__(64, 2) void k2_mcu_lanes(JdKernelArgs a, JdIdctConst K) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
-    if (k2_mode_of(im) != (uint32_t)MODE) return;                  // wave-uniform
+    if (k2_mode_of(im) != (uint32_t)MODE || ((im.flags & JD_IMG_COEF8) != 0) != C8) return;   // wave-uniform
     const uint32_t tile = blockIdx.x - a.prefix[img];
-    if constexpr (MODE == 0) k2m_body<1, 1, 1>(a, im, tile, K);
-    else if constexpr (MODE == 1) k2m_body<1, 1, 3>(a, im, tile, K);
-    else if constexpr (MODE == 2) k2m_body<2, 1, 3>(a, im, tile, K);
-    else if constexpr (MODE == 3) k2m_body<1, 2, 3>(a, im, tile, K);
-    else k2m_body<2, 2, 3>(a, im, tile, K);
+    if constexpr (MODE == 0) k2m_body<1, 1, 1, C8>(a, im, tile, K);
+    else if constexpr (MODE == 1) k2m_body<1, 1, 3, C8>(a, im, tile, K);
+    else if constexpr (MODE == 2) k2m_body<2, 1, 3, C8>(a, im, tile, K);
+    else if constexpr (MODE == 3) k2m_body<1, 2, 3, C8>(a, im, tile, K);
+    else k2m_body<2, 2, 3, C8>(a, im, tile, K);
+}
+
+// byte form -> int16, zig-zag order: what jd_batch_coefficients hands out (one lane per block)
+__global__ __launch_bounds__(256) void k_coef8_expand(JdKernelArgs a, int img, int16_t* __restrict__ out) {
+    const JdImg& im = a.imgs[img];
+    const uint32_t nblocks = im.n_mcus * im.bpm;
+    const uint32_t blk = blockIdx.x * 256u + threadIdx.x;
+    if (blk >= nblocks) return;
+    const uint8_t* lo = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + (uint64_t)blk * 64u;
+    const uint8_t* hi = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + ((uint64_t)nblocks + blk) * 64u;
+    int16_t* o = out + (uint64_t)blk * 64u;
+    const uint32_t b63 = lo[63];
+    const bool wide = (b63 >> 4) == 8u;
+    const int low4 = (int)((int32_t)(b63 << 28) >> 28);
+    o[0] = (int16_t)(((wide ? (int)(int8_t)hi[0] : low4) << 8) | (int)lo[0]);
+    for (int k = 1; k < 63; k++) o[k] = (int16_t)((int)(int8_t)lo[k] + (wide ? ((int)(int8_t)hi[k] << 8) : 0));
+    o[63] = wide ? (int16_t)((low4 << 8) | (int)hi[63]) : (int16_t)((int)(int8_t)b63 >> 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1583,14 +1918,18 @@ void jdk_launch_k0(const JdKernelArgs& a, const uint32_t* d_prefix_k0, uint32_t 
     hipLaunchKernelGGL(k0_unstuff, dim3(wgs), dim3(JD_K0_THREADS), 0, s, x, stride);
 }
 
-void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
+// fmts: bit 0 = some image keeps int16 coefficients, bit 1 = some image uses the byte form
+void jdk_launch_intervals(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
     const uint32_t lds = lb + JD_W_WAVES * JD_WAVE_LDS;
-    if (lds > 64u * 1024u)                                       // > 64 KiB of dynamic LDS needs the attribute (per device)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_intervals), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k1_write_intervals, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
+    if (lds > 64u * 1024u) {                                     // > 64 KiB of dynamic LDS needs the attribute (per device)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_intervals<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_intervals<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (fmts & 1u) hipLaunchKernelGGL(k1_write_intervals<false>, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
+    if (fmts & 2u) hipLaunchKernelGGL(k1_write_intervals<true>, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
 void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int fixup,
@@ -1616,26 +1955,35 @@ void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint3
     hipLaunchKernelGGL(kp_scan, dim3(n), dim3(64), JD_P_RING_DW * 4u + max_lut_bytes, s, a, d_scans, d_list, d_pstream, d_plut);
 }
 
-void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
+void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
     const uint32_t lds = lb + JD_W_WAVES * JD_WAVE_LDS;
-    if (lds > 64u * 1024u)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_subseq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k1_write_subseq, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
+    if (lds > 64u * 1024u) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_subseq<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1_write_subseq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (fmts & 1u) hipLaunchKernelGGL(k1_write_subseq<false>, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
+    if (fmts & 2u) hipLaunchKernelGGL(k1_write_subseq<true>, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
+// modes: bit (2 * m + f): some image has sampling mode m and coefficient form f (0 = int16, 1 = bytes)
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K,
                             hipStream_t s) {
     JdKernelArgs x = a; x.prefix = d_prefix;
     if (!wgs) return;
     const uint32_t lds = 8192 + 8 * 1536;
-    if (modes & 1u) hipLaunchKernelGGL(k2_mcu_lanes<0>, dim3(wgs), dim3(64), lds, s, x, K);
-    if (modes & 2u) hipLaunchKernelGGL(k2_mcu_lanes<1>, dim3(wgs), dim3(64), lds, s, x, K);
-    if (modes & 4u) hipLaunchKernelGGL(k2_mcu_lanes<2>, dim3(wgs), dim3(64), lds, s, x, K);
-    if (modes & 8u) hipLaunchKernelGGL(k2_mcu_lanes<3>, dim3(wgs), dim3(64), lds, s, x, K);
-    if (modes & 16u) hipLaunchKernelGGL(k2_mcu_lanes<4>, dim3(wgs), dim3(64), lds, s, x, K);
+#define JD_K2_LAUNCH(M) \
+    if (modes & (1u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, false>), dim3(wgs), dim3(64), lds, s, x, K); \
+    if (modes & (2u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, true>), dim3(wgs), dim3(64), lds, s, x, K);
+    JD_K2_LAUNCH(0) JD_K2_LAUNCH(1) JD_K2_LAUNCH(2) JD_K2_LAUNCH(3) JD_K2_LAUNCH(4)
+#undef JD_K2_LAUNCH
+}
+
+void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, int16_t* d_out, hipStream_t s) {
+    if (!nblocks) return;
+    hipLaunchKernelGGL(k_coef8_expand, dim3((nblocks + 255u) / 256u), dim3(256), 0, s, a, img, d_out);
 }
 
 }  // extern "C"

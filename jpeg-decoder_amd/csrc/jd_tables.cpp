@@ -105,7 +105,7 @@ int jd_pack_lut_multi(const uint8_t bits[16], const uint8_t* vals, int nvals, un
 }
 
 // Writer table: the same canonical codes in the 32-bit layout of jd_internal.h.
-static inline uint32_t make_entry32(bool is_dc, unsigned sym, unsigned len) {
+static inline uint32_t make_entry32(bool is_dc, unsigned sym, unsigned len, unsigned unit) {
     unsigned size, adv;
     if (is_dc) {
         size = sym;
@@ -114,15 +114,17 @@ static inline uint32_t make_entry32(bool is_dc, unsigned sym, unsigned len) {
     } else {
         const unsigned run = sym >> 4;
         size = sym & 15u;
-        if (sym == 0x00) adv = JD_W32_EOB_ADV;
+        if (sym == 0x00) adv = unit == 2 ? JD_W32_EOB_ADV : JD_W32_EOB_ADV8;
         else if (size == 0 && run != 15) return 0;
-        else adv = 2u * (run + 1u);
+        else adv = unit * (run + 1u);
     }
     const unsigned total = len + size;                 // 1 .. 31
     return (32u - total) | (adv << 8) | (((1u << size) - 1u) << 16);
 }
 
-int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned prim_bits, std::vector<uint32_t>& out) {
+int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned prim_bits, unsigned unit,
+                  std::vector<uint32_t>& out) {
+    if (unit != 1 && unit != 2) return -1;
     const unsigned sec_bits = 16u - prim_bits;                   // a secondary table covers the rest of a 16-bit code
     int count = 0;
     for (int i = 0; i < 16; i++) count += bits[i];
@@ -134,7 +136,7 @@ int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool i
     for (unsigned len = 1; len <= 16; len++) {
         for (int i = 0; i < bits[len - 1]; i++, k++) {
             if (code >= (1u << len)) return -2;
-            const uint32_t e = make_entry32(is_dc, vals[k], len);
+            const uint32_t e = make_entry32(is_dc, vals[k], len, unit);
             if (len <= prim_bits) {
                 const unsigned first = code << (prim_bits - len), n = 1u << (prim_bits - len);
                 for (unsigned j = 0; j < n; j++) out[base + first + j] = e;

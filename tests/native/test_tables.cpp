@@ -48,7 +48,7 @@ static void check_table(const char* name, const uint8_t bits[16], const uint8_t*
         CHECK(jd_pack_lut_bits(bits, vals, nvals, is_dc, lb, t16) == 0, "%s pack16 bits %u", name, lb);
         std::vector<uint32_t> t32;
         const unsigned pb = lb == 12 ? 8 : lb == 11 ? 10 : 9;      // writer-table widths exercised: 9, 10, 8
-        CHECK(jd_pack_lut32(bits, vals, nvals, is_dc, pb, t32) == 0, "%s pack32", name);
+        CHECK(jd_pack_lut32(bits, vals, nvals, is_dc, pb, 2, t32) == 0, "%s pack32", name);
         if (!is_dc) CHECK(jd_pack_lut_multi(bits, vals, nvals, lb, tm) == 0, "%s multi", name);
         for (const Code& c : codes) {
             const unsigned size = is_dc ? c.sym : (c.sym & 15u), run = c.sym >> 4;
