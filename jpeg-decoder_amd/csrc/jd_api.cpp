@@ -453,15 +453,16 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
             if (f.comp[c].td != f.comp[0].td || f.comp[c].ta != f.comp[0].ta) uniform = false;
         if (uniform && f.restart_interval == 0) { im.flags |= JD_IMG_UNIFORM_TABLES; b->any_uniform = true; }
         // Coefficient form.  Bytes (low plane + marked wide blocks in the high plane, write_segments8) halve the traffic
-        // between the Huffman writer and K2, but a wide block (an AC coefficient outside int8, |AC 63| > 7) is decoded
-        // twice: images whose quantisers make that common keep int16 -- an AC coefficient needs |DCT| >= 128 * q to
-        // leave int8 and 8-bit samples cannot reach 1024, so q >= 3 everywhere makes wide blocks an edge-of-a-checkerboard
-        // event.  Uniform-table images keep int16 (k1_dc_scan rewrites DC in place), and so do progressive files
-        // (JD_BATCH_COEF16_: their scans refine coefficients in place).
+        // between the Huffman writer and K2 and let the writer finish a block in one loop, but a wide block (an AC
+        // coefficient outside int8, |AC 63| > 7) costs its wave extra work in both kernels.  An AC coefficient needs
+        // |DCT| >= 128 * q to leave int8.  Measured on C3-shaped images (MI355X, Annex-K tables scaled to a quality): with
+        // every AC quantiser >= 2 (quality <= 92: no or very few wide blocks) bytes win by 10-15 %; with quantisers of 1
+        // (quality 95: 0.7 % of the blocks wide; 98: 2 %) int16 wins by 3 % / 20 %.  Uniform-table images keep int16
+        // (k1_dc_scan rewrites DC in place), and so do progressive files (JD_BATCH_COEF16_: scans refine in place).
         bool bytes = !(im.flags & JD_IMG_UNIFORM_TABLES) && !(flags & JD_BATCH_COEF16_);
         if (bytes && b->coef_form == 0) {
             for (int c = 0; c < f.ncomp && bytes; c++)
-                for (int k = 1; k < 64; k++) if (f.qt[f.comp[c].tq][k] < 3) { bytes = false; break; }
+                for (int k = 1; k < 64; k++) if (f.qt[f.comp[c].tq][k] < 2) { bytes = false; break; }
         } else if (b->coef_form == 16) bytes = false;
         if (bytes) im.flags |= JD_IMG_COEF8;
         b->coef_fmts |= bytes ? 2u : 1u;

@@ -632,15 +632,16 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 //   byte 0       DC, low 8 bits                    byte 63 [3:0]  DC, bits 11..8
 //   bytes 1..62  AC coefficients as int8           byte 63 [7:4]  AC coefficient 63 in -7 .. 7, or 8 = WIDE block
 // A block with an AC magnitude category >= 8 (|v| >= 128), |AC 63| > 7 or a predicted DC outside 12 bits (no 8-bit
-// encoder produces one) is WIDE: its lane decodes it once more, straight from the unstuffed stream in global memory, and
+// encoder produces one) is WIDE: its lane (from the high parts it kept in registers; with more than four such coefficients
+// by decoding the block once more, straight from the unstuffed stream in global memory)
 // writes the block's 64 bytes of the HIGH plane (second half of the image's coefficient region): byte 0 = DC bits 15..8,
 // bytes 1..62 = (v - int8(v)) >> 8 modulo 256 (zero where the low byte says it all), byte 63 = AC 63's low byte -- whose bits 11..8
 // take the DC's place in byte 63 [3:0] of the low plane.  K2 reads the high plane only for blocks that carry the mark.
 // Limits (JD_ST_COEF beyond them, as the int16 form does at 16 bits): DC 16 bits, AC 1..62 16 bits, AC 63 12 bits.
 // (Images whose quantisers make wide blocks common keep the int16 form: jd_api.cpp picks the form per image.)
-// Lines: two consecutive blocks share a 128-byte line.  A lane whose first block has an odd index starts one step late
-// (skew), so that in every lane the block of an even step is the first half of a line: even steps pick up and hold,
-// odd steps pick up and store the line; a half whose partner belongs to another segment goes out as 64 bytes.
+// A block leaves as ONE 64-byte store instruction's worth (4 lanes x 16 B, non-temporal) as soon as it is complete.  (A
+// first version held the even block of a 128-byte line in registers until its partner was ready, as the int16 form does
+// with half blocks: 32 more VGPRs, spills at four waves per SIMD, and 12 % slower than two half-line stores.)
 template <bool NT>
 __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
                                                 const Segment& sg, uint32_t slen, uint32_t err) {
@@ -685,40 +686,31 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     int p0 = sg.p0, p1 = sg.p1, p2 = sg.p2;
     uint32_t c = sg.nblk ? sg.blk0 % bpm : 0u;
     uint32_t bad = 0;
-    // steps: this lane decodes block (st - skew) of its segment at step st, for st in [s_lo, s_hi)
-    const uint32_t s_lo = sg.nblk ? (sg.blk0 & 1u) : 0u, s_hi = s_lo + sg.nblk;
-    uint32_t nsteps = s_hi;
+    uint32_t nsteps = sg.nblk;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nsteps, d, 64); nsteps = t > nsteps ? t : nsteps; }
-    nsteps = (nsteps + 1u) & ~1u;                                          // a line is closed on an odd step
     const uint32_t nblocks = im.n_mcus * bpm;
     uint8_t* const lo_plane = reinterpret_cast<uint8_t*>(a.coef + im.coef_off);
     typedef __attribute__((address_space(1))) uint8_t g_u8;
     g_u8* const hi_plane = (g_u8*)(lo_plane + (uint64_t)nblocks * 64u);
 
-    // flush plan: in pass q lanes 8t'..8t'+7 move the line of lane t = 8q + (lane >> 3); lanes with bit 2 clear hold the
-    // four pieces of the even step's block, the others take the odd step's, then all eight store (those whose block exists)
-    const uint32_t part = lane & 3u, f_hi = (lane >> 2) & 1u;
-    const uint32_t base_blk = sg.blk0 - s_lo;                             // block index at step 0 (even)
-    uint32_t blk_first = sg.nblk ? base_blk : 0xFFFFFFFFu;
+    // flush plan: a block leaves as 64 bytes written by 4 lanes (16 B each) of one store instruction; in pass q lanes
+    // 4t' .. 4t'+3 move the block of lane t = 16q + (lane >> 2)
+    const uint32_t part = lane & 3u;
+    uint32_t blk_first = sg.nblk ? sg.blk0 : 0xFFFFFFFFu;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(blk_first, d, 64); blk_first = t < blk_first ? t : blk_first; }
     blk_first = __builtin_amdgcn_readfirstlane(blk_first == 0xFFFFFFFFu ? 0u : blk_first);
     uint8_t* const wave_dst = lo_plane + (uint64_t)blk_first * 64u;
-    uint32_t f_lo[8], f_end[8], f_off[8];
+    uint32_t f_end[4], f_off[4];
 #pragma unroll
-    for (uint32_t q = 0; q < 8; q++) {
-        const uint32_t t = q * 8u + (lane >> 3);
-        const uint32_t tl = __shfl(s_lo, t, 64), th = __shfl(s_hi, t, 64), tb = __shfl(base_blk, t, 64);
-        // this lane's piece of line (st - 1, st) comes from step st - 1 + f_hi: fold that into the bounds
-        f_lo[q] = tl + 1u - f_hi; f_end[q] = th + 1u - f_hi;
-        f_off[q] = th > tl ? (tb - blk_first) * 64u + (lane & 7u) * 16u : 0u;
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t t = q * 16u + (lane >> 2);
+        f_end[q] = __shfl(sg.nblk, t, 64);
+        const uint32_t tb = __shfl(sg.blk0, t, 64);
+        f_off[q] = f_end[q] ? (tb - blk_first) * 64u + part * 16u : 0u;
     }
-    const uint32_t f_src = wbase + (lane >> 3) * 64u + ((part ^ ((lane >> 3) & 3u)) << 4);   // + q * 512
-    uint4 f_hold[8];
-#pragma unroll
-    for (uint32_t q = 0; q < 8; q++) f_hold[q] = make_uint4(0, 0, 0, 0);
-
+    const uint32_t f_src = wbase + (lane >> 2) * 64u + ((part ^ ((lane >> 2) & 3u)) << 4);   // + q * 1024
     auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rot) >> 4); return q < qmax ? q : qmax; };
     auto request = [&](bool want) {
         const uint32_t used = (wqb >> 4) - (rpb >> 4);
@@ -751,26 +743,40 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         rpb += r ? four : 0u;
     };
     auto flush = [&](uint32_t st) {
-        const uint32_t odd = st & 1u;                                     // wave-uniform
-        if (f_hi == odd) {
 #pragma unroll
-            for (uint32_t q = 0; q < 8; q++) {
-                f_hold[q] = la_u4(f_src + q * 512u);
-                la_st4(f_src + q * 512u, make_uint4(0, 0, 0, 0));
-            }
-        }
-        if (odd) {
-#pragma unroll
-            for (uint32_t q = 0; q < 8; q++) {
-                if (st >= f_lo[q] && st < f_end[q]) {
-                    jd_u32x4 t; t.x = f_hold[q].x; t.y = f_hold[q].y; t.z = f_hold[q].z; t.w = f_hold[q].w;
-                    jd_u32x4* at = reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)(st - 1u) * 64u);
-                    if (NT) __builtin_nontemporal_store(t, at); else *at = t;
-                }
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint4 h = la_u4(f_src + q * 1024u);
+            la_st4(f_src + q * 1024u, make_uint4(0, 0, 0, 0));
+            if (st < f_end[q]) {
+                jd_u32x4 t; t.x = h.x; t.y = h.y; t.z = h.z; t.w = h.w;
+                jd_u32x4* at = reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)st * 64u);
+                if (NT) __builtin_nontemporal_store(t, at); else *at = t;
             }
         }
     };
-    // A wide block, once more: symbols straight from global memory (the ring has moved on), high-plane bytes out.
+    // The high plane of a wide block.  The symbol loop keeps the high parts of up to four coefficients of magnitude
+    // category >= 8 (position << 8 | high part, 16 bits each, in wl0 / wl1); with more than four the block is decoded ...
+    auto wide_from_list = [&](uint32_t blk, int pred, int b63, uint32_t l0, uint32_t l1, uint32_t cnt) -> uint32_t {
+        g_u8* hib = hi_plane + (uint64_t)blk * 64u;
+        typedef __attribute__((address_space(1))) jd_u32x4 g_u4;
+        jd_u32x4 z; z.x = z.y = z.z = z.w = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) ((g_u4*)hib)[i] = z;
+        hib[0] = (uint8_t)((uint32_t)pred >> 8);
+        int hi63 = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            if (i < cnt) {
+                const uint32_t ent = ((i < 2 ? l0 : l1) >> (16u * (i & 1u))) & 0xFFFFu, k = ent >> 8;
+                if (k == 63u) hi63 = (int)(int8_t)ent; else if (k < 63u) hib[k] = (uint8_t)ent;
+            }
+        }
+        const int ac63 = (int)(short)(b63 + hi63 * 256);
+        hib[63] = (uint8_t)ac63;
+        if (ac63 != ((ac63 << 20) >> 20)) err |= JD_ST_COEF;
+        return ((uint32_t)ac63 >> 8) & 15u;
+    };
+    // ... once more: symbols straight from global memory (the ring has moved on), high-plane bytes out.
     auto wide_block = [&](uint32_t pos, uint32_t dcb, uint32_t acb, uint32_t blk, int pred) -> uint32_t {
         const uint32_t* S = reinterpret_cast<const uint32_t*>(a.stream + im.stream_off + JD_STREAM_FRONT);
         const uint32_t imax = (slen + JD_STREAM_TAIL) / 4u - 2u;
@@ -812,13 +818,14 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     const uint32_t idle = 1u << 20;
 #pragma unroll 1
     for (uint32_t st = 0; st < nsteps; st++) {
-        const bool act = st >= s_lo && st < s_hi;
+        const bool act = st < sg.nblk;                                    // this lane decodes block st of its segment at step st
         request(act);
         wave_lds_order();
         const uint32_t comp = c < nl ? 0u : c - nl + 1u;
         const uint32_t dcb = sel3(comp, dc0, dc1, dc2);
         const uint32_t acb = sel3(comp, ac0, ac1, ac2);
-        uint32_t o = idle, e = 0, wacc = 0, wacc_dc = 0, dchi = 0;
+        uint32_t o = idle, e = 0, wl0 = 0, wl1 = 0, wcnt = 0, dchi = 0;
+        bool wide_dc = false;
         int dcv = 0;
         const uint32_t rpb0 = rpb, sh0 = sh;                              // where this block starts (for wide_block)
         if (act) {
@@ -831,7 +838,7 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             const int pred = (int)sel3(comp, (uint32_t)p0, (uint32_t)p1, (uint32_t)p2) + diff;
             p0 = comp == 0 ? pred : p0; p1 = comp == 1 ? pred : p1; p2 = comp >= 2 ? pred : p2;
             if (pred != (int)(short)pred) err |= JD_ST_COEF;             // as the int16 form
-            if (pred != ((pred << 20) >> 20)) wacc_dc = 1u << 23;        // outside 12 bits: a wide block
+            wide_dc = pred != ((pred << 20) >> 20);                      // outside 12 bits: a wide block
             la_st8(slot_b + rot, pred);
             dchi = ((uint32_t)pred >> 8) & 15u;
             dcv = pred;
@@ -847,19 +854,26 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             o += (e >> 8) & 255u;
             const uint32_t at = o < 64u ? slot_b + (o ^ rot) : dump_b;
             la_st8(at, v);
-            wacc |= e;
+            if (__builtin_expect(e >= (1u << 23), 0)) {                  // magnitude category >= 8: keep the high part
+                wl1 = (wl1 << 16) | (wl0 >> 16);
+                wl0 = (wl0 << 16) | ((o & 255u) << 8) | (((uint32_t)(v - (int)(int8_t)v) >> 8) & 0xFFu);
+                wcnt++;
+            }
         }
         if (act) {
             // a block ends at index 63 exactly or by EOB (>= 127); in between = a run that walked past coefficient 63
             if (o > 63u && o < 127u) err |= JD_ST_COEF;
             wave_lds_order();
             const int b63 = la_i8(slot_b + (63u ^ rot));
-            const bool wide = ((wacc | wacc_dc) & (1u << 23)) != 0 || (uint32_t)(b63 + 7) > 14u;
+            const bool wide = wcnt != 0 || wide_dc || (uint32_t)(b63 + 7) > 14u;
             uint32_t low4 = dchi;
             if (__builtin_expect(wide, 0)) {
-                const uint32_t rp = (rpb0 - rot) >> 2;
-                const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - sh0);
-                low4 = wide_block(pos, dcb, acb, base_blk + st, dcv);
+                if (wcnt <= 4u) low4 = wide_from_list(sg.blk0 + st, dcv, b63, wl0, wl1, wcnt);
+                else {
+                    const uint32_t rp = (rpb0 - rot) >> 2;
+                    const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - sh0);
+                    low4 = wide_block(pos, dcb, acb, sg.blk0 + st, dcv);
+                }
             }
             la_st8(slot_b + (63u ^ rot), (int)((wide ? 0x80u : ((uint32_t)b63 << 4)) | low4));
         }
