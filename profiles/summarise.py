@@ -24,7 +24,9 @@ def per_kernel(path, by_counter=False):
     acc, launches = {}, {}
     with open(path) as f:
         for row in csv.DictReader(f):
-            name = row["Kernel_Name"].split("(")[0]
+            # "void k2_mcu_lanes<4, true>(JdKernelArgs, ...)" -> "k2_mcu_lanes": the template instances of one kernel (sampling
+            # mode, coefficient form) are one row; a batch of one kind of image launches exactly one of them
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
             if not name.startswith("k"):
                 continue
             key = (name, row["Counter_Name"]) if by_counter else name
