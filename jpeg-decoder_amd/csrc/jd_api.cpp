@@ -267,7 +267,7 @@ struct jd_batch {
     uint8_t* d_ecs_own = nullptr; uint8_t* d_rgb_own = nullptr; uint8_t* d_stream = nullptr;
     int16_t* d_coef = nullptr; uint16_t* d_lut = nullptr;
     uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
-    unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; JdSubPfx* d_subpfx = nullptr; uint4* d_sync_tot = nullptr;
+    unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; JdSubPfx* d_subpfx = nullptr; JdSubCk* d_subck = nullptr; uint4* d_sync_tot = nullptr;
     uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr;
     // pinned host mirror of the descriptor block, followed by the read-back words (status per image, 64 sync flags)
     uint8_t* h_desc = nullptr; size_t desc_bytes = 0, pre_stride = 0;
@@ -309,7 +309,7 @@ JdKernelArgs kernel_args(const jd_batch* b) {
     JdKernelArgs a;
     a.imgs = b->d_img; a.n_images = b->n; a.prefix = nullptr; a.stream = b->d_stream; a.coef = b->d_coef;
     a.lut = b->d_lut; a.status = b->d_status; a.stream_len = b->d_stream_len; a.interval_start = b->d_interval;
-    a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.subpfx = b->d_subpfx; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
+    a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.subpfx = b->d_subpfx; a.subck = b->d_subck; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
     return a;
 }
 
@@ -566,6 +566,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     A(&b->d_ticket, ((size_t)n_images + 64) * 4);
     A(&b->d_sub, (size_t)subb * sizeof(JdSub));
     A(&b->d_subpfx, (size_t)subb * sizeof(JdSubPfx));
+    A(&b->d_subck, (size_t)subb * sizeof(JdSubCk));
     A(&b->d_sync_tot, (size_t)swb * sizeof(uint4));
     if (rc == JD_OK) {
         b->d_img = reinterpret_cast<JdImg*>(b->d_desc);

@@ -136,6 +136,20 @@ struct JdSub {
     int32_t dc[3];               // sum of their DC differences, per component
     uint32_t pad;
 };
+// Checkpoints of a sub-sequence's FIRST full decode (k1_sync round 1): where that decode stood at the first block start past
+// every fifth of the sub-sequence (state and running counts) plus its totals and exit state -- one self-consistent trajectory.  A later decode of the same
+// sub-sequence from a corrected entry state stops at the first checkpoint whose state it reproduces (from there on it IS
+// that trajectory) and takes the rest of the counts from the record.
+#define JD_CK_N 4
+struct JdSubCk {
+    uint32_t state[JD_CK_N];     // bits left << 12 | block-in-MCU << 8 | zig-zag index (0 = no checkpoint)
+    uint32_t nstart[JD_CK_N];    // blocks started so far
+    int32_t dc[JD_CK_N][3];      // DC-difference sums so far
+    uint32_t tot_nstart, tot_exit;
+    int32_t tot_dc[3];
+    uint32_t pad[7];
+};
+static_assert(sizeof(JdSubCk) == 128, "JdSubCk");
 // packed state: [7:0] bit offset past the sub-sequence start, [15:8] block-in-MCU, [23:16] zig-zag index,
 // bit 31 = valid
 #define JD_STATE_VALID 0x80000000u
@@ -167,6 +181,7 @@ struct JdKernelArgs {
     uint32_t* k0_ticket;         // per image: next chunk to hand out
     JdSub* sub;
     JdSubPfx* subpfx;
+    JdSubCk* subck;              // per sub-sequence: checkpoints of its first full decode
     uint4* sync_tot;             // per sync workgroup: (block starts, dc0, dc1, dc2) totals -> exclusive prefix after spine
     uint32_t* changed;           // sync: set when a workgroup's exit state changed
 };

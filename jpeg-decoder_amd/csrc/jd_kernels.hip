@@ -952,9 +952,15 @@ __device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<
 #ifndef JD_COLD_BITS
 #define JD_COLD_BITS 2048u
 #endif
-template <bool COLD>
+// MODE 0 = COLD (above); 1 = a sub-sequence's first full decode: records its checkpoints (JdSubCk, taken at block
+// starts); 2 = a later decode from a corrected entry state: stops at the first checkpoint whose state it reproduces and
+// completes its counts from the record.
+__device__ __forceinline__ uint32_t ck_state(int left, uint32_t c, uint32_t z) { return ((uint32_t)left << 12) | (c << 8) | z; }
+template <int MODE>
 __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, const uint16_t* __restrict__ lutg,
-                                            uint32_t s, uint32_t entry, uint32_t sbits, bool run, JdSub& rec) {
+                                            uint32_t s, uint32_t entry, uint32_t sbits, bool run, JdSub& rec,
+                                            JdSubCk* __restrict__ ck = nullptr, bool use_ck = false) {
+    constexpr bool COLD = MODE == 0;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ring_l = JD_SY_RINGS + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * JD_SPEC_RING_BYTES + lane * 4u;
     auto ring_at = [&](uint32_t xb) { return lds_u32(ring_l | (xb & (JD_SPEC_RING_BYTES - 1u))); };
@@ -969,29 +975,27 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     // ring bookkeeping in units of 256 bytes per dword (= the [dword][lane] row pitch)
     uint32_t rpb = (g & 3u) * 256u, wqb = 0;
     auto top_up = [&]() {                                                 // every lane fills every free quad
-        uint4 v[4]; bool take[4];
-        const uint32_t used = (wqb >> 10) - (rpb >> 10);                  // quads holding unread dwords
+        constexpr uint32_t NQ = JD_SPEC_RING_DW / 4u;                     // quads in the ring
+        const uint32_t used = (wqb >> 10) - (rpb >> 10);                  // quads holding unread dwords (<= NQ)
+        // the loads are unconditional (a lane with no free quad reads one it will not keep): under per-lane branches
+        // hipcc waits for each load before it issues the next, NQ memory latencies instead of one
+        uint4 v[NQ];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            take[k] = run && used + (uint32_t)k < JD_SPEC_RING_DW / 4u;
-            const uint32_t q = qbase + (wqb >> 10) + (uint32_t)k;
-            v[k] = make_uint4(0, 0, 0, 0);
-            if (take[k]) v[k] = Q[q < qmax ? q : qmax];
+        for (uint32_t k = 0; k < NQ; k++) {
+            const uint32_t q = qbase + (wqb >> 10) + k;
+            v[k] = Q[q < qmax ? q : qmax];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (take[k]) {
-                const uint32_t x = wqb + (uint32_t)k * 1024u;
+        for (uint32_t k = 0; k < NQ; k++) {
+            if (run && used + k < NQ) {
+                const uint32_t x = wqb + k * 1024u;
                 *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | (x & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].x);
                 *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 256u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].y);
                 *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 512u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].z);
                 *reinterpret_cast<uint32_t*>(dyn_lds + (ring_l | ((x + 768u) & (JD_SPEC_RING_BYTES - 1u)))) = be32(v[k].w);
             }
         }
-        uint32_t n = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) n += take[k] ? 1u : 0u;
-        wqb += n * 1024u;
+        wqb += run ? (NQ - used) * 1024u : 0u;
         wave_lds_order();
     };
     top_up();
@@ -1006,6 +1010,19 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     uint32_t nstart = 0, first = 0;
     *lds_int(dcs_l) = 0; *lds_int(dcs_l + JD_SYNC_WG * 4u) = 0; *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u) = 0;
     wave_lds_order();
+    // use_ck (per lane): the sub-sequence is one this workgroup owns.  A warm-up lane decodes a sub-sequence of the
+    // workgroup before -- whose record that workgroup is writing at this very moment -- so it neither records nor stops early.
+    //
+    //
+    // The decode is FREE-RUNNING: every lane walks its own symbols (DC and AC alike) in one loop.  (A block-synchronous
+    // walk -- DC bookkeeping and table switch once per block for all lanes -- measured 2 % slower: waiting for the
+    // wave's longest block costs what the leaner loop saves.)
+    constexpr int kCkStep = (int)(JD_SUBSEQ_BITS / (JD_CK_N + 1));       // MODE 1: a checkpoint at the first block start past
+    int thr = (int)JD_SUBSEQ_BITS - kCkStep;                             //         every kCkStep bits of the sub-sequence
+    uint32_t ckj = 0;
+    uint32_t tgt = 0, tj = 0;                                             // MODE 2: pending checkpoint's state and index
+    int matched = -1;
+    if (MODE == 2 && run && use_ck) tgt = ck->state[0];
     while (left > 0) {
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up();
         const uint32_t cand = ring_at(rpb);
@@ -1020,6 +1037,28 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
         uint32_t total = e & 31u;
         uint32_t zn = z + ((e >> 5) & 127u);                              // AC entries: A + 64 * E (jd_tables.cpp)
         if (z == 0) {                                                     // a block starts here: DC difference
+            if (MODE == 1 && use_ck && left <= thr) {                     // (per lane, a few times per sub-sequence)
+                if (ckj < JD_CK_N) {
+                    wave_lds_order();
+                    ck->state[ckj] = ck_state(left, c, 0); ck->nstart[ckj] = nstart;
+                    ck->dc[ckj][0] = *lds_int(dcs_l); ck->dc[ckj][1] = *lds_int(dcs_l + JD_SYNC_WG * 4u);
+                    ck->dc[ckj][2] = *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u);
+                    ckj++;
+                }
+                thr -= kCkStep;
+            }
+            if (MODE == 2) {
+                const uint32_t cur = ck_state(left, c, 0);
+                while (__builtin_expect(cur <= tgt, 0)) {                 // at or past the pending checkpoint
+                    if (cur == tgt) { matched = (int)tj; break; }
+                    tj++;                                                 // passed it: wait for the next one
+                    tgt = tj < JD_CK_N ? ck->state[tj < JD_CK_N ? tj : 0] : 0u;
+                }
+                if (matched >= 0) {                                       // from here on this decode IS the recorded one
+                    if (nstart == 0) first = (uint32_t)left;
+                    break;
+                }
+            }
             if (!COLD) {
                 if (nstart == 0) first = (uint32_t)left;                  // kept as "bits left" at that point
                 nstart++;
@@ -1029,10 +1068,10 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
         } else if (zn >= 64u) {
             // the block ends in this group: fine if it ends with the group (index 64 reached by its last symbol, or
             // EOB before index 64); if the block filled up INSIDE the group, the rest of the group belongs to the
-            // next block -- redo the step with one symbol from the writer's table
+            // next block -- redo the step with one symbol from the single-symbol table
             const bool ok = zn == 64u || (zn - z >= 64u && zn < 128u);
             if (!ok) {
-                const uint16_t* gt = lutg + sel3(t >> 30, ik.ac0, ik.ac1, ik.ac2);   // single-symbol table (global memory)
+                const uint16_t* gt = lutg + sel3(t >> 30, ik.ac0, ik.ac1, ik.ac2);   // (global memory)
                 uint32_t e1 = gt[win >> (32 - JD_LUT_BITS)];
                 if (e1 & 0x8000u) e1 = (e1 & 0x7FFFu) ? gt[(e1 & 0x7FFFu) + ((win >> (32 - JD_LUT_BITS - 6)) & 63u)] : 0u;
                 if (e1 == 0) e1 = 1;
@@ -1057,8 +1096,21 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
         rec.entry = entry;
         rec.exit = pack_state((uint32_t)(-left), c, z);
         rec.nstart = nstart;
-        rec.first = nstart ? (end - start) - first + (entry & 0xFFu) : 0u;   // bit offset from the sub-sequence start
+        if (MODE == 2 && matched >= 0) rec.nstart += ck->tot_nstart - ck->nstart[matched];   // (the recorded decode's block starts from here on)
+        rec.first = rec.nstart ? (end - start) - first + (entry & 0xFFu) : 0u;   // bit offset from the sub-sequence start
         rec.dc[0] = *lds_int(dcs_l); rec.dc[1] = *lds_int(dcs_l + JD_SYNC_WG * 4u); rec.dc[2] = *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u);
+        if (MODE == 1 && use_ck) {
+            // checkpoints the decode did not reach stay invalid; the totals close the record
+            for (uint32_t j = ckj; j < JD_CK_N; j++) ck->state[j] = 0u;
+            ck->tot_nstart = rec.nstart; ck->tot_exit = rec.exit;
+            ck->tot_dc[0] = rec.dc[0]; ck->tot_dc[1] = rec.dc[1]; ck->tot_dc[2] = rec.dc[2];
+        }
+        if (MODE == 2 && matched >= 0) {
+            // from the checkpoint on this decode IS the recorded one: its exit state, its remaining counts
+            rec.exit = ck->tot_exit;
+            rec.dc[0] += ck->tot_dc[0] - ck->dc[matched][0]; rec.dc[1] += ck->tot_dc[1] - ck->dc[matched][1];
+            rec.dc[2] += ck->tot_dc[2] - ck->dc[matched][2];
+        }
     }
 }
 
@@ -1066,7 +1118,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
 // on the JD_SYNC_WARM sub-sequences before them (results discarded).
 // warm_off (debug knob, JD_DEBUG_SYNC_NO_WARM): the warm-up lanes stay idle, so that every workgroup boundary depends on
 // the fix-up launches -- lets a test drive the host's extra fix-up loop.
-__global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup, int flag_slot, int warm_off) {
+__global__ __launch_bounds__(JD_SYNC_WG, 6) void k1_sync(JdKernelArgs a, int fixup, int flag_slot, int warm_off) {
     __shared__ uint32_t ex[JD_SYNC_WG];
     __shared__ uint32_t tmp[16];
     // re-decode list and its results (gathered rounds): they live in the stream rings of the waves that idle while the
@@ -1108,7 +1160,7 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
     else {
         // blind decode: only its exit state is kept; entry 0 (not a valid state) makes every lane decode again
         // from its neighbour's exit in the first round of the loop below
-        spec_decode<true>(ik, Q, qmax, a.lut + im.lut_off, s, start_state, sbits, active && s != 0, rec);
+        spec_decode<0>(ik, Q, qmax, a.lut + im.lut_off, s, start_state, sbits, active && s != 0, rec);
         rec.entry = 0;
     }
     const uint32_t exit_before = rec.exit;
@@ -1137,17 +1189,23 @@ __global__ __launch_bounds__(JD_SYNC_WG) void k1_sync(JdKernelArgs a, int fixup,
         const uint32_t wv = threadIdx.x >> 6;
         const uint32_t pos = (wv > 0 ? n0 : 0u) + (wv > 1 ? n1 : 0u) + (wv > 2 ? n2 : 0u) +
                              (uint32_t)__popcll(bm & ((1ull << (threadIdx.x & 63u)) - 1ull));
-        uint32_t s_x = s, e_x = ne; bool run_x = changed;
+        uint32_t s_x = s, e_x = ne; bool run_x = changed, own_x = owned;
         if (gather) {
-            if (changed) { re_src[pos] = s; re_ent[pos] = ne; }
+            if (changed) { re_src[pos] = s | (owned ? 0x80000000u : 0u); re_ent[pos] = ne; }
             __syncthreads();
             run_x = threadIdx.x < n;
             s_x = run_x ? re_src[threadIdx.x] : 0u;
             e_x = run_x ? re_ent[threadIdx.x] : 0u;
+            own_x = (s_x >> 31) != 0; s_x &= 0x7FFFFFFFu;
         }
         JdSub r2 = rec;
-        if (__builtin_amdgcn_ballot_w64(run_x))                  // wave-uniform: skip waves with nothing to redo
-            spec_decode<false>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2);
+        JdSubCk* const ckp = a.subck + im.subseq_base + s_x;
+        if (__builtin_amdgcn_ballot_w64(run_x)) {                // wave-uniform: skip waves with nothing to redo
+            // the first round of the first launch is every sub-sequence's first full decode: it leaves the checkpoints
+            // that every later decode (later rounds, gathered or not, and the fix-up launches) stops at
+            if (!fixup && it == 0) spec_decode<1>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2, ckp, own_x);
+            else spec_decode<2>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2, ckp, own_x);
+        }
         if (gather) {
             if (run_x) {
                 re_out[threadIdx.x][0] = r2.exit; re_out[threadIdx.x][1] = r2.nstart; re_out[threadIdx.x][2] = r2.first;
