@@ -22,6 +22,7 @@
 #include "jd_internal.h"
 
 #define WAVE 64
+typedef uint32_t jd_u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -123,21 +124,41 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     // Workgroups that are resident together should belong to different images (their tickets, status words and
     // look-back chains are per image): blockIdx is spread over the images by a stride coprime to the grid size --
     // any permutation will do, an image only needs as many workgroups as it has chunks.
-    const int img = find_image(a.prefix, a.n_images, (uint32_t)(((unsigned long long)blockIdx.x * stride) % gridDim.x));
+    const int img = __builtin_amdgcn_readfirstlane(find_image(a.prefix, a.n_images, (uint32_t)(((unsigned long long)blockIdx.x * stride) % gridDim.x)));
     const JdImg& im = a.imgs[img];
     if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket + img, 1u);
+    // the segment's address and length go through scalar registers (readfirstlane: the descriptor loads are waited for
+    // HERE, once, not again at every branch below) and the address is a global-memory one (a generic pointer makes flat loads)
+    typedef __attribute__((address_space(1))) const uint8_t g_cu8;
+    typedef __attribute__((address_space(1))) const jd_u32x4 g_cq;
+    const uint64_t ecs_bits = (uint64_t)(uintptr_t)im.ecs;
+    // (readfirstlane returns int: each half goes through uint32_t, or the low half's sign bit would fill the high one)
+    const uint32_t ecs_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ecs_bits >> 32));
+    const uint32_t ecs_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ecs_bits);
+    g_cu8* const ecs = (g_cu8*)(uintptr_t)(((uint64_t)ecs_hi << 32) | (uint64_t)ecs_lo);
+    const uint32_t len = __builtin_amdgcn_readfirstlane(im.ecs_len);
+    const uint32_t gbase = a.prefix[img];                        // (these descriptor reads overlap the ticket's round trip)
     __syncthreads();
     const uint32_t chunk = s_chunk;
-    const uint32_t gchunk = a.prefix[img] + chunk;
-    const uint8_t* __restrict__ ecs = im.ecs;
-    const uint32_t len = im.ecs_len, c0 = chunk * JD_K0_CHUNK;
-    // ---- stage the chunk: coalesced 16-byte loads (0xD9 past the end: behaves like EOI) ------------------
+    const uint32_t gchunk = gbase + chunk;
+    const uint32_t c0 = chunk * JD_K0_CHUNK;
+    // ---- stage the chunk: coalesced 16-byte loads (0xD9 past the end: behaves like EOI).  All of a lane's loads are
+    // issued before any is used: with load and LDS write in one loop body hipcc waited for each quad before it issued
+    // the next -- two memory latencies per chunk instead of one.
+    uint4 stg[JD_K0_QUADS];
 #pragma unroll
     for (int r = 0; r < JD_K0_QUADS; r++) {
         const uint32_t q = (uint32_t)r * JD_K0_THREADS + threadIdx.x, g = c0 + q * 16u;
-        uint4 v = make_uint4(0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u);
-        if (g + 16u <= len) v = *reinterpret_cast<const uint4*>(ecs + g);
-        else if (g < len) {
+        stg[r] = make_uint4(0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u);
+        if (g + 16u <= len) { const jd_u32x4 t = *(g_cq*)(ecs + g); stg[r] = make_uint4(t.x, t.y, t.z, t.w); }
+    }
+    const uint32_t edge_prev = c0 > 0 ? ecs[c0 - 1] : 0u;
+    const uint32_t edge_next = c0 + JD_K0_CHUNK < len ? ecs[c0 + JD_K0_CHUNK] : 0xD9u;
+#pragma unroll
+    for (int r = 0; r < JD_K0_QUADS; r++) {
+        const uint32_t q = (uint32_t)r * JD_K0_THREADS + threadIdx.x, g = c0 + q * 16u;
+        uint4 v = stg[r];
+        if (__builtin_expect(g < len && g + 16u > len, 0)) {      // the segment's ragged end: byte by byte (one lane per image)
             uint32_t t[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
             for (int j = 0; j < 16; j++)
@@ -146,8 +167,6 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
         }
         *reinterpret_cast<uint4*>(raw + q * 16u) = v;
     }
-    const uint32_t edge_prev = c0 > 0 ? ecs[c0 - 1] : 0u;
-    const uint32_t edge_next = c0 + JD_K0_CHUNK < len ? ecs[c0 + JD_K0_CHUNK] : 0xD9u;
     __syncthreads();
     // ---- classify this thread's 64 contiguous bytes --------------------------------------------------------
     const uint32_t t0 = threadIdx.x * 16u * JD_K0_QUADS;         // byte offset inside the chunk
@@ -372,7 +391,6 @@ __device__ __forceinline__ uint32_t lut_lookup(uint32_t tb, uint32_t win, uint32
 typedef __attribute__((address_space(3))) uint8_t* jd_lds_ptr;
 __device__ __forceinline__ uint32_t lds_abs_base() { return (uint32_t)(uintptr_t)(jd_lds_ptr)dyn_lds; }
 __device__ __forceinline__ uint32_t la_u32(uint32_t addr) { return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)addr; }
-typedef uint32_t jd_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 la_u4(uint32_t addr) {
     const jd_u32x4 v = *(__attribute__((address_space(3))) const jd_u32x4*)(uintptr_t)addr;
     return make_uint4(v.x, v.y, v.z, v.w);
