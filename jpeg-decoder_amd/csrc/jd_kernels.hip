@@ -126,18 +126,25 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     // any permutation will do, an image only needs as many workgroups as it has chunks.
     const int img = __builtin_amdgcn_readfirstlane(find_image(a.prefix, a.n_images, (uint32_t)(((unsigned long long)blockIdx.x * stride) % gridDim.x)));
     const JdImg& im = a.imgs[img];
-    if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket + img, 1u);
-    // the segment's address and length go through scalar registers (readfirstlane: the descriptor loads are waited for
-    // HERE, once, not again at every branch below) and the address is a global-memory one (a generic pointer makes flat loads)
+    // The image's descriptor fields are read FIRST (plain vector loads, in flight while lane 0 takes the ticket) and go
+    // through scalar registers afterwards (readfirstlane: waited for once, here, not again at every branch below); the
+    // segment's address becomes a global-memory one (a generic pointer makes flat loads).
     typedef __attribute__((address_space(1))) const uint8_t g_cu8;
     typedef __attribute__((address_space(1))) const jd_u32x4 g_cq;
-    const uint64_t ecs_bits = (uint64_t)(uintptr_t)im.ecs;
+    const uint64_t ecs_bits = (uint64_t)(uintptr_t)im.ecs, soff_bits = im.stream_off;
+    const uint32_t len_v = im.ecs_len, nch_v = im.n_k0_chunks, nint_v = im.n_intervals, ivb_v = im.interval_base;
+    const uint32_t gbase = a.prefix[img];
+    asm volatile("" :: "v"(len_v), "v"(nch_v) : "memory");      // (issued before the atomic below, not sunk behind it)
+    if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket + img, 1u);
     // (readfirstlane returns int: each half goes through uint32_t, or the low half's sign bit would fill the high one)
     const uint32_t ecs_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ecs_bits >> 32));
     const uint32_t ecs_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ecs_bits);
     g_cu8* const ecs = (g_cu8*)(uintptr_t)(((uint64_t)ecs_hi << 32) | (uint64_t)ecs_lo);
-    const uint32_t len = __builtin_amdgcn_readfirstlane(im.ecs_len);
-    const uint32_t gbase = a.prefix[img];                        // (these descriptor reads overlap the ticket's round trip)
+    const uint32_t len = __builtin_amdgcn_readfirstlane(len_v);
+    const uint32_t n_chunks = __builtin_amdgcn_readfirstlane(nch_v), n_intervals = __builtin_amdgcn_readfirstlane(nint_v);
+    const uint32_t iv_base = __builtin_amdgcn_readfirstlane(ivb_v);
+    const uint64_t stream_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(soff_bits >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)soff_bits);
     __syncthreads();
     const uint32_t chunk = s_chunk;
     const uint32_t gchunk = gbase + chunk;
@@ -231,12 +238,12 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
         if (lane == 0) {
             if (chunk) __hip_atomic_store(st, (run + mine) | JD_K0_PFX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base = make_uint2((uint32_t)(run & 0xFFFFFFFull), (uint32_t)((run >> 28) & 0xFFFFFFFull));
-            if (chunk + 1 == im.n_k0_chunks) {                   // last chunk of the image: totals
+            if (chunk + 1 == n_chunks) {                   // last chunk of the image: totals
                 const uint32_t total = (uint32_t)((run + mine) & 0xFFFFFFFull), nrst = (uint32_t)(((run + mine) >> 28) & 0xFFFFFFFull);
                 a.stream_len[img] = total;
-                a.interval_start[im.interval_base] = 0;
-                a.interval_start[im.interval_base + im.n_intervals] = total;
-                if (nrst != im.n_intervals - 1) atomicOr(&a.status[img], JD_ST_RST_COUNT);
+                a.interval_start[iv_base] = 0;
+                a.interval_start[iv_base + n_intervals] = total;
+                if (nrst != n_intervals - 1) atomicOr(&a.status[img], JD_ST_RST_COUNT);
             }
         }
     }
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
                     const uint32_t sh = 31u - (uint32_t)__builtin_clz(bit) - 7u;      // 8j
                     const uint32_t nk = ridx + 1;                // interval that starts after this marker
                     const uint32_t off = kb + __popc(keep[r][k] & (bit - 1u));
-                    if (nk < im.n_intervals) a.interval_start[im.interval_base + nk] = off;
+                    if (nk < n_intervals) a.interval_start[iv_base + nk] = off;
                     if (((w[r][k] >> sh) & 7u) != (ridx & 7u)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
                     ridx++;
                 }
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     // (the barrier after the look-back also orders the compaction's LDS writes before the reads below)
     // ---- LDS -> stream: whole 16-byte quads, bytes at the two ragged ends.  Output byte i of the aligned window
     // (i = 0 at the 16-byte boundary below the chunk's first output byte) is buf[i - al] -------------------------------
-    uint8_t* dst = a.stream + im.stream_off + JD_STREAM_FRONT + (base.x - al);   // 16-byte aligned
+    uint8_t* dst = a.stream + stream_off + JD_STREAM_FRONT + (base.x - al);   // 16-byte aligned
     const uint32_t lo = al, hi = al + tk;                        // valid byte range of the window
     const uint32_t qlo = (lo + 15u) >> 4, qhi = hi >> 4;         // whole quads [qlo, qhi)
     const uint32_t bsh = (0u - al) & 3u;                         // byte shift inside a dword (uniform)
