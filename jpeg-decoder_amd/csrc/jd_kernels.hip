@@ -1709,6 +1709,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     // dyn_lds + i * 1024 + lane * 16, and the next block's eight pieces are in flight while this one is computed.
     // dyn_lds + 8192 .. : the left luma block's RGB rows wait here (24 B per lane and row) for the right one.
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stage_base = lds_abs_base() + 8192u + lane * 24u;  // LDS byte address of this lane's parked row 0
     auto block_of = [&](uint32_t st) { return st < (uint32_t)(NC - 1) ? NL + st : st - (uint32_t)(NC - 1); };   // chroma first
     auto fetch = [&](uint32_t st) {
         const uint4* src = cbase + block_of(st) * (uint32_t)NP;
@@ -1724,12 +1725,15 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     for (uint32_t st = 0; st < BPM; st++) {
         const uint32_t b = __builtin_amdgcn_readfirstlane(block_of(st));
         const uint32_t comp = b < NL ? 0u : b - NL + 1u;
-        // the quantisation table is wave-uniform: scalar loads (a vector load here would also drain the DMA queue)
+        // the quantisation table is wave-uniform: read through the constant address space so that it IS a scalar load
+        // (s_load_dwordx16).  As a plain global read hipcc made four vector loads + readfirstlane, and their vmcnt(0)
+        // wait also drained the LDS-DMA queue at the top of every block.
         uint32_t qw[16];
         {
-            const uint32_t* qp = reinterpret_cast<const uint32_t*>(im.q[comp]);
+            typedef __attribute__((address_space(4))) const uint32_t c_u32;
+            c_u32* qp = (c_u32*)(uintptr_t)(im.q[comp]);
 #pragma unroll
-            for (int i = 0; i < 16; i++) qw[i] = __builtin_amdgcn_readfirstlane(qp[i]);
+            for (int i = 0; i < 16; i++) qw[i] = qp[i];
         }
         uint32_t cw[NP * 4];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1754,6 +1758,11 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 g_cu4* hp = hbase + b * 4u;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const jd_u32x4 v = hp[i]; hw[i * 4] = v.x; hw[i * 4 + 1] = v.y; hw[i * 4 + 2] = v.z; hw[i * 4 + 3] = v.w; }
+                // "use" them here: hipcc then waits for these loads inside this rare branch.  Left pending they made it
+                // put a vmcnt(0) in front of the column pass of EVERY block (their registers are reused there), which also
+                // waited for the next block's DMA, issued just below -- the prefetch never overlapped anything.
+                asm volatile("" : "+v"(hw[0]), "+v"(hw[1]), "+v"(hw[2]), "+v"(hw[3]), "+v"(hw[4]), "+v"(hw[5]), "+v"(hw[6]), "+v"(hw[7]));
+                asm volatile("" : "+v"(hw[8]), "+v"(hw[9]), "+v"(hw[10]), "+v"(hw[11]), "+v"(hw[12]), "+v"(hw[13]), "+v"(hw[14]), "+v"(hw[15]));
             }
         }
         if (st + 1u < BPM) fetch(st + 1u);
@@ -1913,16 +1922,21 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 window(std::integral_constant<int, 1>{});
 #endif
                 if (Yp < H && pair) {
-                    uint8_t* stage = dyn_lds + 8192u + (uint32_t)i * 1536u + lane * 24u;
+                    // The parked rows go to LDS and back through asm: hipcc cannot tell this area from the one the LDS-DMA
+                    // writes, so before every ds access of its own it waits for vmcnt(0) -- the next block's DMA AND every
+                    // pixel store issued so far, once per pixel row.  (LDS operations of one wave execute in order.)
+                    const uint32_t sa = stage_base + (uint32_t)i * 1536u;
                     if (bx == 0) {
-                        *reinterpret_cast<uint2*>(stage) = make_uint2(d[0], d[1]);
-                        *reinterpret_cast<uint2*>(stage + 8) = make_uint2(d[2], d[3]);
-                        *reinterpret_cast<uint2*>(stage + 16) = make_uint2(d[4], d[5]);
+                        const uint64_t p0 = d[0] | ((uint64_t)d[1] << 32), p1 = d[2] | ((uint64_t)d[3] << 32), p2 = d[4] | ((uint64_t)d[5] << 32);
+                        asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8\n\tds_write_b64 %0, %3 offset:16"
+                                     :: "v"(sa), "v"(p0), "v"(p1), "v"(p2) : "memory");
                     } else {
-                        const uint2 l0 = *reinterpret_cast<const uint2*>(stage), l1 = *reinterpret_cast<const uint2*>(stage + 8);
-                        const uint2 l2 = *reinterpret_cast<const uint2*>(stage + 16);
+                        uint64_t l0, l1, l2;
+                        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(l0), "=&v"(l1), "=&v"(l2) : "v"(sa) : "memory");
                         g_u4* o = (g_u4*)(rgbp + (uint64_t)Yp * rs + X0 * 3u);
-                        o[0] = u32x4{ l0.x, l0.y, l1.x, l1.y }; o[1] = u32x4{ l2.x, l2.y, d[0], d[1] };
+                        o[0] = u32x4{ (uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)l1, (uint32_t)(l1 >> 32) };
+                        o[1] = u32x4{ (uint32_t)l2, (uint32_t)(l2 >> 32), d[0], d[1] };
                         o[2] = u32x4{ d[2], d[3], d[4], d[5] };
                     }
                 } else if (Yp < H) {
