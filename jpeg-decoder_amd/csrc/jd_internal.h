@@ -141,15 +141,14 @@ struct JdSub {
 // sub-sequence from a corrected entry state stops at the first checkpoint whose state it reproduces (from there on it IS
 // that trajectory) and takes the rest of the counts from the record.
 #define JD_CK_N 4
-struct JdSubCk {
-    uint32_t state[JD_CK_N];     // bits left << 12 | block-in-MCU << 8 | zig-zag index (0 = no checkpoint)
-    uint32_t nstart[JD_CK_N];    // blocks started so far
-    int32_t dc[JD_CK_N][3];      // DC-difference sums so far
-    uint32_t tot_nstart, tot_exit;
-    int32_t tot_dc[3];
-    uint32_t pad[7];
+struct JdCkEntry {               // 32 bytes: written with two 16-byte non-temporal stores, never in parts
+    uint32_t state;              // bits left << 12 | block-in-MCU << 8 | zig-zag index (0 = no checkpoint); totals: exit state
+    uint32_t nstart;             // blocks started so far (totals: in the whole sub-sequence)
+    int32_t dc[3];               // DC-difference sums so far (totals: of the whole sub-sequence)
+    uint32_t pad[3];
 };
-static_assert(sizeof(JdSubCk) == 128, "JdSubCk");
+struct JdSubCk { JdCkEntry e[JD_CK_N + 1]; };   // [JD_CK_N] = the decode's totals and exit state
+static_assert(sizeof(JdSubCk) == 32 * (JD_CK_N + 1), "JdSubCk");
 // packed state: [7:0] bit offset past the sub-sequence start, [15:8] block-in-MCU, [23:16] zig-zag index,
 // bit 31 = valid
 #define JD_STATE_VALID 0x80000000u

@@ -981,6 +981,14 @@ __device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<
 // starts); 2 = a later decode from a corrected entry state: stops at the first checkpoint whose state it reproduces and
 // completes its counts from the record.
 __device__ __forceinline__ uint32_t ck_state(int left, uint32_t c, uint32_t z) { return ((uint32_t)left << 12) | (c << 8) | z; }
+// one checkpoint = two whole 16-byte non-temporal stores (stores of parts of a line make L2 fetch the line first)
+__device__ __forceinline__ void ck_store(JdCkEntry* e, uint32_t state, uint32_t nstart, int d0, int d1, int d2) {
+    jd_u32x4 lo, hi;
+    lo.x = state; lo.y = nstart; lo.z = (uint32_t)d0; lo.w = (uint32_t)d1;
+    hi.x = (uint32_t)d2; hi.y = 0; hi.z = 0; hi.w = 0;
+    __builtin_nontemporal_store(lo, reinterpret_cast<jd_u32x4*>(e));
+    __builtin_nontemporal_store(hi, reinterpret_cast<jd_u32x4*>(e) + 1);
+}
 template <int MODE>
 __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, const uint16_t* __restrict__ lutg,
                                             uint32_t s, uint32_t entry, uint32_t sbits, bool run, JdSub& rec,
@@ -1002,12 +1010,13 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     auto top_up = [&]() {                                                 // every lane fills every free quad
         constexpr uint32_t NQ = JD_SPEC_RING_DW / 4u;                     // quads in the ring
         const uint32_t used = (wqb >> 10) - (rpb >> 10);                  // quads holding unread dwords (<= NQ)
-        // the loads are unconditional (a lane with no free quad reads one it will not keep): under per-lane branches
-        // hipcc waits for each load before it issues the next, NQ memory latencies instead of one
+        // the loads are unconditional: under per-lane branches hipcc waits for each load before it issues the next, NQ
+        // memory latencies instead of one.  A lane with no room for quad k reads the stream's first quad instead (one
+        // line for everybody: always a cache hit), not a quad it would have to fetch again later.
         uint4 v[NQ];
 #pragma unroll
         for (uint32_t k = 0; k < NQ; k++) {
-            const uint32_t q = qbase + (wqb >> 10) + k;
+            const uint32_t q = (run && used + k < NQ) ? qbase + (wqb >> 10) + k : 0u;
             v[k] = Q[q < qmax ? q : qmax];
         }
 #pragma unroll
@@ -1047,7 +1056,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     uint32_t ckj = 0;
     uint32_t tgt = 0, tj = 0;                                             // MODE 2: pending checkpoint's state and index
     int matched = -1;
-    if (MODE == 2 && run && use_ck) tgt = ck->state[0];
+    if (MODE == 2 && run && use_ck) tgt = ck->e[0].state;
     while (left > 0) {
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up();
         const uint32_t cand = ring_at(rpb);
@@ -1065,9 +1074,8 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
             if (MODE == 1 && use_ck && left <= thr) {                     // (per lane, a few times per sub-sequence)
                 if (ckj < JD_CK_N) {
                     wave_lds_order();
-                    ck->state[ckj] = ck_state(left, c, 0); ck->nstart[ckj] = nstart;
-                    ck->dc[ckj][0] = *lds_int(dcs_l); ck->dc[ckj][1] = *lds_int(dcs_l + JD_SYNC_WG * 4u);
-                    ck->dc[ckj][2] = *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u);
+                    ck_store(&ck->e[ckj], ck_state(left, c, 0), nstart, *lds_int(dcs_l), *lds_int(dcs_l + JD_SYNC_WG * 4u),
+                             *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u));
                     ckj++;
                 }
                 thr -= kCkStep;
@@ -1077,7 +1085,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
                 while (__builtin_expect(cur <= tgt, 0)) {                 // at or past the pending checkpoint
                     if (cur == tgt) { matched = (int)tj; break; }
                     tj++;                                                 // passed it: wait for the next one
-                    tgt = tj < JD_CK_N ? ck->state[tj < JD_CK_N ? tj : 0] : 0u;
+                    tgt = tj < JD_CK_N ? ck->e[tj < JD_CK_N ? tj : 0].state : 0u;
                 }
                 if (matched >= 0) {                                       // from here on this decode IS the recorded one
                     if (nstart == 0) first = (uint32_t)left;
@@ -1121,20 +1129,19 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
         rec.entry = entry;
         rec.exit = pack_state((uint32_t)(-left), c, z);
         rec.nstart = nstart;
-        if (MODE == 2 && matched >= 0) rec.nstart += ck->tot_nstart - ck->nstart[matched];   // (the recorded decode's block starts from here on)
+        if (MODE == 2 && matched >= 0) rec.nstart += ck->e[JD_CK_N].nstart - ck->e[matched].nstart;   // (the recorded decode's block starts from here on)
         rec.first = rec.nstart ? (end - start) - first + (entry & 0xFFu) : 0u;   // bit offset from the sub-sequence start
         rec.dc[0] = *lds_int(dcs_l); rec.dc[1] = *lds_int(dcs_l + JD_SYNC_WG * 4u); rec.dc[2] = *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u);
         if (MODE == 1 && use_ck) {
             // checkpoints the decode did not reach stay invalid; the totals close the record
-            for (uint32_t j = ckj; j < JD_CK_N; j++) ck->state[j] = 0u;
-            ck->tot_nstart = rec.nstart; ck->tot_exit = rec.exit;
-            ck->tot_dc[0] = rec.dc[0]; ck->tot_dc[1] = rec.dc[1]; ck->tot_dc[2] = rec.dc[2];
+            for (uint32_t j = ckj; j < JD_CK_N; j++) ck_store(&ck->e[j], 0u, 0u, 0, 0, 0);
+            ck_store(&ck->e[JD_CK_N], rec.exit, rec.nstart, rec.dc[0], rec.dc[1], rec.dc[2]);
         }
         if (MODE == 2 && matched >= 0) {
             // from the checkpoint on this decode IS the recorded one: its exit state, its remaining counts
-            rec.exit = ck->tot_exit;
-            rec.dc[0] += ck->tot_dc[0] - ck->dc[matched][0]; rec.dc[1] += ck->tot_dc[1] - ck->dc[matched][1];
-            rec.dc[2] += ck->tot_dc[2] - ck->dc[matched][2];
+            const JdCkEntry tot = ck->e[JD_CK_N], at = ck->e[matched];
+            rec.exit = tot.state;
+            rec.dc[0] += tot.dc[0] - at.dc[0]; rec.dc[1] += tot.dc[1] - at.dc[1]; rec.dc[2] += tot.dc[2] - at.dc[2];
         }
     }
 }
