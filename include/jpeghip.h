@@ -149,6 +149,10 @@ int jd_batch_run(jd_batch* b, void* hip_stream);
 int jd_batch_wait(jd_batch* b);
 int jd_batch_status(const jd_batch* b, int image);
 int jd_batch_download(jd_batch* b, int image, uint8_t* rgb_out, size_t row_stride);
+/* Quantised coefficients of one image as int16 (layout of jd_decode_coefficients).  On the device they travel from the
+ * Huffman kernels to the IDCT kernel in a byte form when the image's quantisers allow it; this call
+ * expands them, on the device, into a temporary it allocates and frees.  Limits of the stored forms, beyond which the
+ * image's status is JD_E_COEF: DC and AC 1..62 16 bits, AC 63 16 bits (int16 form) / 12 bits (byte form). */
 int jd_batch_coefficients(jd_batch* b, int image, int16_t* coef_out, size_t coef_cap);
 
 /* ---- pinned-memory pipeline (the reference's file loop main.go:1509-1512 + writer
