@@ -749,14 +749,15 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         if (npend >= 2) la_st4(ring_b | ((wqb + 16u) & 63u), be32x4(pq1));
         wqb += npend * 16u; npend = 0;
     };
+    // A lane whose read pointer caught up with its write pointer gets quads on the spot (rare).  Its pending request is
+    // DROPPED, not committed: with the commit's byte swap of the requested quads visible inside the symbol loop, hipcc
+    // hoists it -- and the wait for the loads -- in front of the loop that is there to hide them.
     auto top_up_now = [&]() {
         if (rpb >= wqb) {
-            commit();
-            if (rpb >= wqb) {
-                const uint4 v = Q[quad_index(wqb)];
-                la_st4(ring_b | (wqb & 63u), be32x4(v));
-                wqb += 16u;
-            }
+            npend = 0;
+            const uint4 v = Q[quad_index(wqb)];
+            la_st4(ring_b | (wqb & 63u), be32x4(v));
+            wqb += 16u;
         }
         wave_lds_order();
     };
