@@ -1,6 +1,6 @@
 """GPU: seeded random sweep over geometry x sampling x quality x restart interval x coefficient form x table sharing,
 coefficients against the encoder's own and pixels against the oracle (the no-DRI twin for DRI files).
-exp/fuzz_parity.py is the open-ended form of the same loop (2,938 cases without a mismatch on the round-2 build)."""
+tests/fuzz_parity.py is the open-ended form of the same loop (2,938 cases without a mismatch on the round-2 build)."""
 import os
 import random
 
