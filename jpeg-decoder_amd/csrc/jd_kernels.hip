@@ -36,27 +36,34 @@ __device__ __forceinline__ int find_image(const uint32_t* __restrict__ prefix, i
     return lo;
 }
 
+// Inclusive scan over the wave in six DPP additions (row shifts 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of
+// rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3): no LDS round trips (six ds_bpermute before).
+#define JD_DPP(v, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xF, false))
+__device__ __forceinline__ uint32_t row_incl_scan(uint32_t v) {      // inside each row of 16 lanes
+    v += JD_DPP(v, 0x111, 0xF);                                       // row_shr:1
+    v += JD_DPP(v, 0x112, 0xF);                                       // row_shr:2
+    v += JD_DPP(v, 0x114, 0xF);                                       // row_shr:4
+    v += JD_DPP(v, 0x118, 0xF);                                       // row_shr:8
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v = row_incl_scan(v);
+    v += JD_DPP(v, 0x142, 0xA);                                       // row_bcast:15 into rows 1 and 3
+    v += JD_DPP(v, 0x143, 0xC);                                       // row_bcast:31 into rows 2 and 3
     return v;
 }
 
 // exclusive scan over a thread block (<= 1024); `tmp` has >= 16 words of LDS; returns block total in `total`
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t& total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = wave_incl_scan(v);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t inc = wave_incl_scan(v);
     __syncthreads();
     if (lane == 63) tmp[wv] = inc;
     __syncthreads();
-    uint32_t base = 0, tot = 0;
-    const int nw = (blockDim.x + 63) >> 6;
-    for (int w = 0; w < nw; w++) { uint32_t t = tmp[w]; if (w < wv) base += t; tot += t; }
-    total = tot;
+    const int nw = (int)((blockDim.x + 63u) >> 6);                    // <= 16: the wave totals fit one row
+    const uint32_t t = row_incl_scan(lane < nw ? tmp[lane] : 0u);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)t, nw - 1);
+    const uint32_t base = wv ? (uint32_t)__builtin_amdgcn_readlane((int)t, wv - 1) : 0u;
     return base + inc - v;
 }
 
@@ -77,35 +84,36 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 #ifndef JD_K0_WAVES_PER_SIMD
 #define JD_K0_WAVES_PER_SIMD 6
 #endif
-#define JD_K0_QUADS (JD_K0_CHUNK / (JD_K0_THREADS * 16))        // 16-byte quads per thread
-static_assert(JD_K0_CHUNK == JD_K0_THREADS * 16 * JD_K0_QUADS, "chunk size");
+#define JD_K0_LANE_BYTES (JD_K0_CHUNK / JD_K0_THREADS)          // contiguous bytes per lane
+static_assert(JD_K0_LANE_BYTES == 32, "one 32-bit flag mask per lane");
 
-__device__ __forceinline__ uint32_t zero_flags(uint32_t x) {   // 0x80 in every byte of x that is zero (exact)
-    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    return ~(t | x | 0x7F7F7F7Fu);
+// 0x80 in every byte of x that is NOT zero (exact: no carries between bytes)
+__device__ __forceinline__ uint32_t nonzero_flags(uint32_t x) {
+    return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
 }
-
-// keep / rst flag words (0x80 in byte j = byte j of the quad) and a non-zero `bad` if a non-RST marker follows FF
-__device__ __forceinline__ void k0_classify(const uint32_t (&w)[4], uint32_t prev, uint32_t next, uint32_t n,
-                                            uint32_t (&keep)[4], uint32_t (&rst)[4], uint32_t& bad) {
-    uint32_t F[4], Z[4], R[4];
+// The flag words of a lane's eight dwords -> one bit per byte.  v_dot4_u32_u8 against the byte weights 1,2,4,8 (even
+// dword) / 16,32,64,128 (odd dword) sums 0x80 * weight over the flagged bytes: 128 * (8-bit mask) per dword pair.
+__device__ __forceinline__ uint32_t k0_gather(const uint32_t (&f)[8]) {
+    uint32_t g[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        F[k] = zero_flags(~w[k]); Z[k] = zero_flags(w[k]); R[k] = zero_flags((w[k] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u);
-    }
-    const uint32_t Fm1 = prev == 0xFFu ? 0x80000000u : 0u, Z4 = next == 0u ? 0x80u : 0u;
-    bad = 0;
+    for (int p = 0; p < 4; p++)
+        g[p] = __builtin_amdgcn_udot4(f[2 * p + 1], 0x80402010u, __builtin_amdgcn_udot4(f[2 * p], 0x08040201u, 0u, false), false);
+    return (g[0] >> 7) | (g[1] << 1) | (g[2] << 9) | (g[3] << 17);
+}
+// lane i <- lane i - 1 (lane 0 <- fill) / lane i <- lane i + 1 (lane 63 <- fill): DPP wave shifts, no LDS round trip
+__device__ __forceinline__ uint32_t wave_from_below(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);   // wave_shr:1
+}
+__device__ __forceinline__ uint32_t wave_from_above(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);   // wave_shl:1
+}
+// v_perm selector that moves the kept bytes (4-bit mask m) of a dword to its low end; the rest reads as 0
+__device__ __forceinline__ uint32_t k0_squeeze_selector(uint32_t m) {
+    uint32_t sel = 0x0C0C0C0Cu, n = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t PF = __builtin_amdgcn_alignbit(F[k], k ? F[k - 1] : Fm1, 24);       // previous byte is FF
-        const uint32_t NZ = __builtin_amdgcn_alignbit(k < 3 ? Z[k + 1] : Z4, Z[k], 8);     // next byte is 00
-        const uint32_t lo = 4u * (uint32_t)k;
-        const uint32_t V = n >= lo + 4u ? 0x80808080u : (n <= lo ? 0u : (0x80808080u & ((1u << (8u * (n - lo))) - 1u)));
-        const uint32_t after = ~F[k] & PF & V;                                             // non-FF byte right after an FF
-        keep[k] = ((F[k] & NZ) | (~F[k] & ~PF)) & V;
-        rst[k] = after & R[k];
-        bad |= after & ~Z[k] & ~R[k];
-    }
+    for (uint32_t j = 0; j < 4; j++)
+        if (m & (1u << j)) { sel = (sel & ~(0xFFu << (8u * n))) | (j << (8u * n)); n++; }
+    return sel;
 }
 
 // status word of a chunk: [27:0] kept bytes, [55:28] RSTn markers, [63:62] 1 = this chunk alone, 2 = inclusive prefix
@@ -116,8 +124,8 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     __shared__ uint32_t tmp[16];
     __shared__ uint32_t s_chunk;
     __shared__ uint2 s_base;
-    __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 32];   // first the raw chunk, then (after the scan's barriers) the compacted one
-    uint8_t* const raw = buf;
+    __shared__ uint32_t s_sel[16];
+    __shared__ __align__(16) uint8_t buf[JD_K0_CHUNK + 32];   // the compacted chunk (the raw one never touches LDS)
     // blockIdx picks the image; the chunk inside it is the next ticket of THAT image (one counter for the whole
     // batch saturates at ~90 tickets/us -- measured 80 us for 7,200 chunks), so a chunk's predecessors have
     // always started before it
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     const uint32_t gbase = a.prefix[img];
     asm volatile("" :: "v"(len_v), "v"(nch_v) : "memory");      // (issued before the atomic below, not sunk behind it)
     if (threadIdx.x == 0) s_chunk = atomicAdd(a.k0_ticket + img, 1u);
+    if (threadIdx.x < 16) s_sel[threadIdx.x] = k0_squeeze_selector(threadIdx.x);
     // (readfirstlane returns int: each half goes through uint32_t, or the low half's sign bit would fill the high one)
     const uint32_t ecs_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ecs_bits >> 32));
     const uint32_t ecs_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ecs_bits);
@@ -149,54 +158,60 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     const uint32_t chunk = s_chunk;
     const uint32_t gchunk = gbase + chunk;
     const uint32_t c0 = chunk * JD_K0_CHUNK;
-    // ---- stage the chunk: coalesced 16-byte loads (0xD9 past the end: behaves like EOI).  All of a lane's loads are
-    // issued before any is used: with load and LDS write in one loop body hipcc waited for each quad before it issued
-    // the next -- two memory latencies per chunk instead of one.
-    uint4 stg[JD_K0_QUADS];
+    const uint32_t lane = threadIdx.x & 63u;
+    // ---- this lane's 32 contiguous bytes, straight into registers (0xD9 past the end: behaves like EOI).  Two 16-byte
+    // loads per lane, 32 bytes apart between lanes: each 128-byte line is touched by both and fetched once.  The byte
+    // before the wave's first and the byte after its last come with the same batch of loads (lanes 0-31 read the one,
+    // lanes 32-63 the other; only lanes 0 and 63 use them); inside the wave the neighbours' flags travel by DPP.
+    const uint32_t g0 = c0 + threadIdx.x * JD_K0_LANE_BYTES;     // offset of this lane's bytes in the segment
+    uint32_t w[8];
+    jd_u32x4 stg[2];
 #pragma unroll
-    for (int r = 0; r < JD_K0_QUADS; r++) {
-        const uint32_t q = (uint32_t)r * JD_K0_THREADS + threadIdx.x, g = c0 + q * 16u;
-        stg[r] = make_uint4(0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u);
-        if (g + 16u <= len) { const jd_u32x4 t = *(g_cq*)(ecs + g); stg[r] = make_uint4(t.x, t.y, t.z, t.w); }
+    for (int r = 0; r < 2; r++) {
+        const uint32_t g = g0 + 16u * (uint32_t)r;
+        stg[r] = jd_u32x4{0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u};
+        if (g + 16u <= len) stg[r] = *(g_cq*)(ecs + g);
     }
-    const uint32_t edge_prev = c0 > 0 ? ecs[c0 - 1] : 0u;
-    const uint32_t edge_next = c0 + JD_K0_CHUNK < len ? ecs[c0 + JD_K0_CHUNK] : 0xD9u;
+    const uint32_t wave0 = g0 - lane * JD_K0_LANE_BYTES;         // offset of the wave's first byte
+    const uint32_t eaddr = lane < 32u ? wave0 - 1u : wave0 + 64u * JD_K0_LANE_BYTES;
+    uint32_t edge = lane < 32u ? 0u : 0xD9u;                     // before the segment: not FF; past its end: not 00
+    if (lane < 32u ? wave0 != 0u && wave0 <= len : eaddr < len) edge = ecs[eaddr];
 #pragma unroll
-    for (int r = 0; r < JD_K0_QUADS; r++) {
-        const uint32_t q = (uint32_t)r * JD_K0_THREADS + threadIdx.x, g = c0 + q * 16u;
-        uint4 v = stg[r];
+    for (int r = 0; r < 2; r++) {
+        const uint32_t g = g0 + 16u * (uint32_t)r;
+        uint32_t t[4] = { stg[r].x, stg[r].y, stg[r].z, stg[r].w };
         if (__builtin_expect(g < len && g + 16u > len, 0)) {      // the segment's ragged end: byte by byte (one lane per image)
-            uint32_t t[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 if (g + (uint32_t)j < len) t[j >> 2] = (t[j >> 2] & ~(0xFFu << ((j & 3) * 8))) | ((uint32_t)ecs[g + j] << ((j & 3) * 8));
-            v = make_uint4(t[0], t[1], t[2], t[3]);
         }
-        *reinterpret_cast<uint4*>(raw + q * 16u) = v;
-    }
-    __syncthreads();
-    // ---- classify this thread's 64 contiguous bytes --------------------------------------------------------
-    const uint32_t t0 = threadIdx.x * 16u * JD_K0_QUADS;         // byte offset inside the chunk
-    uint32_t w[JD_K0_QUADS][4], keep[JD_K0_QUADS][4], rstf[JD_K0_QUADS][4];
-    uint32_t bad = 0, nk = 0, nr = 0;
 #pragma unroll
-    for (int r = 0; r < JD_K0_QUADS; r++) {
-        const uint4 v = *reinterpret_cast<const uint4*>(raw + t0 + r * 16);
-        w[r][0] = v.x; w[r][1] = v.y; w[r][2] = v.z; w[r][3] = v.w;
+        for (int k = 0; k < 4; k++) w[4 * r + k] = t[k];
     }
+    // ---- classify: one bit per byte ------------------------------------------------------------------------
+    uint32_t fl[8];
 #pragma unroll
-    for (int r = 0; r < JD_K0_QUADS; r++) {
-        const uint32_t o = t0 + (uint32_t)r * 16u, g = c0 + o;
-        const uint32_t prev = r ? (w[r - 1][3] >> 24) : (o ? raw[o - 1] : edge_prev);
-        const uint32_t next = r + 1 < JD_K0_QUADS ? (w[r + 1][0] & 0xFFu) : (o + 16u < JD_K0_CHUNK ? raw[o + 16u] : edge_next);
-        const uint32_t n = g < len ? (len - g < 16u ? len - g : 16u) : 0u;
-        uint32_t bq;
-        k0_classify(w[r], prev, next, n, keep[r], rstf[r], bq);
-        bad |= bq;
+    for (int k = 0; k < 8; k++) fl[k] = nonzero_flags(~w[k]);
+    const uint32_t notF = k0_gather(fl);                         // byte is not FF
 #pragma unroll
-        for (int k = 0; k < 4; k++) { nk += __popc(keep[r][k]); nr += __popc(rstf[r][k]); }
-    }
-    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&a.status[img], JD_ST_MARKER);
+    for (int k = 0; k < 8; k++) fl[k] = nonzero_flags(w[k]);
+    const uint32_t notZ = k0_gather(fl);                         // byte is not 00
+#pragma unroll
+    for (int k = 0; k < 8; k++) fl[k] = nonzero_flags((w[k] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u);
+    const uint32_t notR = k0_gather(fl);                         // byte is not D0..D7
+    const uint32_t F = ~notF, Z = ~notZ;
+    const uint32_t below = wave_from_below(F, edge == 0xFFu ? 0x80000000u : 0u);    // bit 31: the byte before mine is FF
+    const uint32_t above = wave_from_above(Z, edge == 0u ? 1u : 0u);                // bit 0: the byte after mine is 00
+    const uint32_t PF = __builtin_amdgcn_alignbit(F, below, 31);                    // previous byte is FF
+    const uint32_t NZ = __builtin_amdgcn_alignbit(above, Z, 1);                     // next byte is 00
+    const uint32_t n = g0 < len ? (len - g0 < 32u ? len - g0 : 32u) : 0u;           // bytes of mine inside the segment
+    const uint32_t V = n >= 32u ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    const uint32_t after = notF & PF & V;                                            // non-FF byte right after an FF
+    const uint32_t keep = ((F & NZ) | (notF & ~PF)) & V;
+    const uint32_t rst = after & ~notR;
+    const uint32_t bad = after & notZ & notR;
+    const uint32_t nk = __popc(keep), nr = __popc(rst);
+    if (__any(bad != 0) && lane == 0) atomicOr(&a.status[img], JD_ST_MARKER);
     uint32_t tot;
     const uint32_t ex = block_excl_scan(nk | (nr << 16), tmp, tot);   // nk <= 64 * 256 < 2^16 per workgroup
     const uint32_t ek = ex & 0xFFFFu, er = ex >> 16, tk = tot & 0xFFFFu, tr = tot >> 16;
@@ -207,16 +222,34 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     unsigned long long* st = a.k0_state + gchunk;
     const unsigned long long mine = (unsigned long long)tk | ((unsigned long long)tr << 28);
     if (threadIdx.x == 0) __hip_atomic_store(st, mine | (chunk ? JD_K0_AGG : JD_K0_PFX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Compaction: a dword's kept bytes are squeezed to its low end by one v_perm (selector from a 16-entry table) and
+    // the dword is stored at its BYTE offset in the compacted chunk (LDS takes unaligned dword writes on gfx950:
+    // exp/lds_unaligned.hip).  The bytes above the kept ones are rubbish; the lane's next dword overwrites them (same
+    // wave, LDS executes in order).  A dword whose rubbish would reach past the lane's last kept byte -- into bytes the
+    // next lane wrote in an EARLIER instruction -- is written byte by byte instead: only ever one of the lane's last
+    // dwords, and only when fewer than four kept bytes follow its first.
     {
-        uint32_t o = ek;
+        const uint32_t buf_b = (uint32_t)(uintptr_t)buf + ek, sel_b = (uint32_t)(uintptr_t)s_sel;
+        uint32_t sel[8];
 #pragma unroll
-        for (int r = 0; r < JD_K0_QUADS; r++)
+        for (int k = 0; k < 8; k++)                              // all eight table reads first: one LDS latency, not eight
+            sel[k] = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(sel_b + ((keep >> (4 * k)) & 15u) * 4u);
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                if (keep[r][j >> 2] & (0x80u << ((j & 3) * 8))) buf[o++] = (uint8_t)(w[r][j >> 2] >> ((j & 3) * 8));
+        for (int k = 0; k < 8; k++) {
+            const uint32_t c = __builtin_amdgcn_perm(0u, w[k], sel[k]);
+            const uint32_t at = buf_b + (k ? __popc(keep & ((1u << (4 * k)) - 1u)) : 0u);
+            const uint32_t rem = __popc(keep >> (4 * k));        // kept bytes from this dword on
+            if (rem >= 4u) asm volatile("ds_write_b32 %0, %1" :: "v"(at), "v"(c) : "memory");
+            else {
+                const uint32_t cnt = __popc((keep >> (4 * k)) & 15u);
+                if (cnt > 0u) asm volatile("ds_write_b8 %0, %1" :: "v"(at), "v"(c) : "memory");
+                if (cnt > 1u) asm volatile("ds_write_b8 %0, %1 offset:1" :: "v"(at), "v"(c >> 8) : "memory");
+                if (cnt > 2u) asm volatile("ds_write_b8 %0, %1 offset:2" :: "v"(at), "v"(c >> 16) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (threadIdx.x < 64) {                                      // wave 0
-        const uint32_t lane = threadIdx.x;
         unsigned long long run = 0;                              // sum of the chunks before this one
         int back = (int)chunk - 1;                               // nearest chunk not yet summed
         while (back >= 0) {
@@ -252,24 +285,19 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     // ---- index the restart markers --------------------------------------------------------------------------------
     const uint32_t al = base.x & 15u;
     if (nr) {                                                    // markers are rare: walk the set flags only
-        uint32_t ridx = base.y + er, kb = base.x + ek;           // markers / kept bytes before the current quad
-#pragma unroll
-        for (int r = 0; r < JD_K0_QUADS; r++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t f = rstf[r][k];
-                while (f) {
-                    const uint32_t bit = f & (0u - f);           // lowest marker byte of this dword (0x80 << 8j)
-                    f ^= bit;
-                    const uint32_t sh = 31u - (uint32_t)__builtin_clz(bit) - 7u;      // 8j
-                    const uint32_t nk = ridx + 1;                // interval that starts after this marker
-                    const uint32_t off = kb + __popc(keep[r][k] & (bit - 1u));
-                    if (nk < n_intervals) a.interval_start[iv_base + nk] = off;
-                    if (((w[r][k] >> sh) & 7u) != (ridx & 7u)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
-                    ridx++;
-                }
-                kb += __popc(keep[r][k]);
-            }
+        uint32_t f = rst, ridx = base.y + er;                    // markers before the current one
+        const uint32_t kb = base.x + ek;                         // kept bytes before this lane's
+        while (f) {
+            const uint32_t pos = (uint32_t)__builtin_ctz(f);     // the Dn byte
+            f &= f - 1u;
+            const uint32_t i = pos >> 2;
+            const uint32_t a0 = i & 1u ? w[1] : w[0], a1 = i & 1u ? w[3] : w[2], a2 = i & 1u ? w[5] : w[4], a3 = i & 1u ? w[7] : w[6];
+            const uint32_t b0 = i & 2u ? a1 : a0, b1 = i & 2u ? a3 : a2;
+            const uint32_t digit = ((i & 4u ? b1 : b0) >> ((pos & 3u) * 8u)) & 7u;
+            const uint32_t nxt = ridx + 1;                       // interval that starts after this marker
+            if (nxt < n_intervals) a.interval_start[iv_base + nxt] = kb + __popc(keep & ((1u << pos) - 1u));
+            if (digit != (ridx & 7u)) atomicOr(&a.status[img], JD_ST_RST_SEQ);
+            ridx++;
         }
     }
     // (the barrier after the look-back also orders the compaction's LDS writes before the reads below)
