@@ -59,9 +59,9 @@
 
 // unstuff pass: bytes per workgroup
 #ifndef JD_K0_THREADS
-#define JD_K0_THREADS 512
+#define JD_K0_THREADS 1024
 #endif
-#define JD_K0_CHUNK 16384
+#define JD_K0_CHUNK (JD_K0_THREADS * 32)
 
 // unstuffed stream: bytes of padding in front of / behind each image's data
 #define JD_STREAM_FRONT 16

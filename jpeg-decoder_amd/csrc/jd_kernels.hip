@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, u
 //   FF followed by FF      -> fill byte, drop the first FF
 //   FF followed by other   -> marker inside the segment: error (main.go:1013-1016)
 // ------------------------------------------------------------------------------------------------
-// One pass, one kernel (k0_unstuff): every workgroup takes the next 16 KiB chunk of the batch (ticket counter, so
+// One pass, one kernel (k0_unstuff): every workgroup (1024 lanes) takes the next 32 KiB chunk of its image (ticket counter, so
 // chunks start in order), classifies its bytes four at a time with SWAR flag words, scans the kept-byte and
 // marker counts, and learns its output offset by DECOUPLED LOOK-BACK over the per-chunk status words of the
 // chunks before it (aggregate / inclusive-prefix in one 8-byte word, written and read with agent-scope
