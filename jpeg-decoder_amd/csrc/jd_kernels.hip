@@ -306,15 +306,20 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     uint8_t* dst = a.stream + stream_off + JD_STREAM_FRONT + (base.x - al);   // 16-byte aligned
     const uint32_t lo = al, hi = al + tk;                        // valid byte range of the window
     const uint32_t qlo = (lo + 15u) >> 4, qhi = hi >> 4;         // whole quads [qlo, qhi)
-    const uint32_t bsh = (0u - al) & 3u;                         // byte shift inside a dword (uniform)
-    for (uint32_t q = qlo + threadIdx.x; q < qhi; q += JD_K0_THREADS) {
-        const uint32_t p = q * 16u - al;                         // first source byte; five aligned dwords cover the 16
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(buf + (p & ~3u));
-        const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2], d3 = sp[3], d4 = sp[4];
-        uint4 v;
-        v.x = __builtin_amdgcn_alignbyte(d1, d0, bsh); v.y = __builtin_amdgcn_alignbyte(d2, d1, bsh);
-        v.z = __builtin_amdgcn_alignbyte(d3, d2, bsh); v.w = __builtin_amdgcn_alignbyte(d4, d3, bsh);
-        reinterpret_cast<uint4*>(dst)[q] = v;
+    // (LDS takes a 16-byte read at any byte address on gfx950 -- exp/lds_unaligned128.hip; through asm, so that the
+    // reads of both rounds are in flight together)
+    const uint32_t src_b = (uint32_t)(uintptr_t)buf - al;
+    static_assert(JD_K0_CHUNK / 16 + 1 <= 3 * JD_K0_THREADS, "copy-out rounds");
+    {
+        const uint32_t q0 = qlo + threadIdx.x, q1 = q0 + JD_K0_THREADS, q2 = q1 + JD_K0_THREADS;
+        jd_u32x4 v0 = {}, v1 = {}, v2 = {};
+        if (q0 < qhi) asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(src_b + q0 * 16u) : "memory");
+        if (q1 < qhi) asm volatile("ds_read_b128 %0, %1" : "=v"(v1) : "v"(src_b + q1 * 16u) : "memory");
+        if (q2 < qhi) asm volatile("ds_read_b128 %0, %1" : "=v"(v2) : "v"(src_b + q2 * 16u) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2) :: "memory");
+        if (q0 < qhi) reinterpret_cast<jd_u32x4*>(dst)[q0] = v0;
+        if (q1 < qhi) reinterpret_cast<jd_u32x4*>(dst)[q1] = v1;
+        if (q2 < qhi) reinterpret_cast<jd_u32x4*>(dst)[q2] = v2;
     }
     if (threadIdx.x < 32) {
         uint32_t i;
