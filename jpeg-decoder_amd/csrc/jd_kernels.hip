@@ -1898,7 +1898,11 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                     }
             }
         }
-        const uint32_t bx = b % HS, by = b / HS;
+        const uint32_t bx = b % HS;
+        uint32_t by = b / HS;
+        // (VS = 1: by is always 0, the eight row addresses become loop invariants, hipcc hoists them and the 4:2:2
+        // kernel spills 79 registers.  Laundered through a scalar register they are computed where they are used.)
+        asm volatile("" : "+s"(by));
         const uint32_t X = X0 + bx * 8u;
         if (X >= W) continue;
         const bool full = al8 && X + 8u <= W;
@@ -1966,15 +1970,16 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                     // The parked rows go to LDS and back through asm: hipcc cannot tell this area from the one the LDS-DMA
                     // writes, so before every ds access of its own it waits for vmcnt(0) -- the next block's DMA AND every
                     // pixel store issued so far, once per pixel row.  (LDS operations of one wave execute in order.)
-                    const uint32_t sa = stage_base + (uint32_t)i * 1536u;
+                    // (row i at stage_base + i * 1536: the row offset rides in the instruction's offset field -- as eight
+                    // separate addresses hipcc keeps eight loop-invariant registers for them)
                     if (bx == 0) {
                         const uint64_t p0 = d[0] | ((uint64_t)d[1] << 32), p1 = d[2] | ((uint64_t)d[3] << 32), p2 = d[4] | ((uint64_t)d[5] << 32);
-                        asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8\n\tds_write_b64 %0, %3 offset:16"
-                                     :: "v"(sa), "v"(p0), "v"(p1), "v"(p2) : "memory");
+                        asm volatile("ds_write_b64 %0, %1 offset:%4\n\tds_write_b64 %0, %2 offset:%5\n\tds_write_b64 %0, %3 offset:%6"
+                                     :: "v"(stage_base), "v"(p0), "v"(p1), "v"(p2), "n"(i * 1536), "n"(i * 1536 + 8), "n"(i * 1536 + 16) : "memory");
                     } else {
                         uint64_t l0, l1, l2;
-                        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(l0), "=&v"(l1), "=&v"(l2) : "v"(sa) : "memory");
+                        asm volatile("ds_read_b64 %0, %3 offset:%4\n\tds_read_b64 %1, %3 offset:%5\n\tds_read_b64 %2, %3 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(l0), "=&v"(l1), "=&v"(l2) : "v"(stage_base), "n"(i * 1536), "n"(i * 1536 + 8), "n"(i * 1536 + 16) : "memory");
                         g_u4* o = (g_u4*)(rgbp + (uint64_t)Yp * rs + X0 * 3u);
                         o[0] = u32x4{ (uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)l1, (uint32_t)(l1 >> 32) };
                         o[1] = u32x4{ (uint32_t)l2, (uint32_t)(l2 >> 32), d[0], d[1] };
