@@ -245,6 +245,20 @@ int jd_decode_scans_coefficients(const jd_frame* frame, const jd_scan* scans, in
  * 818-888, 942-987) and returns the frame plus the extent of the stuffed entropy-coded segment
  * (start offset and length, EOI excluded). */
 int jd_parse(const uint8_t* file, size_t file_len, jd_frame* frame, size_t* ecs_off, size_t* ecs_len);
+/* Restart-interval-range sharding.  No counterpart in the reference (it has no restart handling, SURVEY
+ * F3).  Cuts a DRI image into at most `parts` bands of whole MCU rows that decode independently -- each on its own GPU if
+ * wanted: band k is an image of its own (bands[k].frame: the caller's frame with the band's height) whose stuffed
+ * entropy-coded segment is ecs[ecs_off .. ecs_off + ecs_len) (the RSTn in front of it and the one behind it belong to no
+ * band) and whose pixel rows go to rows y0 .. y0 + frame.height of the picture.  Every entry point above takes a band
+ * as it takes an image.  Needs restart_interval > 0 dividing the MCUs per row (else JD_E_UNSUPPORTED); boundaries are
+ * placed so that every band's first marker is RST0 again.  *n_bands <= parts (a picture has only so many MCU rows).
+ * JD_E_RESTART if the segment holds fewer, or wrongly numbered, markers than the cuts need. */
+typedef struct jd_band {
+    jd_frame frame;
+    size_t ecs_off, ecs_len;
+    uint32_t y0;
+} jd_band;
+int jd_split_bands(const jd_frame* frame, const uint8_t* ecs, size_t ecs_len, int parts, jd_band* bands, int* n_bands);
 /* BMP exactly as writeBitMap lays it out (main.go:1171-1218): returns the file size; writes it if
  * out != NULL and cap is large enough. */
 long jd_bmp_encode(const uint8_t* rgb, size_t row_stride, int width, int height, uint8_t* out, size_t cap);

@@ -42,6 +42,11 @@ class Scan(ctypes.Structure):
                 ("huff", (Huff * 4) * 2)]
 
 
+class Band(ctypes.Structure):
+    """jd_band: a run of whole MCU rows of a DRI image that decodes on its own (jd_split_bands)."""
+    _fields_ = [("frame", Frame), ("ecs_off", ctypes.c_size_t), ("ecs_len", ctypes.c_size_t), ("y0", ctypes.c_uint32)]
+
+
 # every symbol include/jpeghip.h declares (tests/test_abi.py checks the library exports exactly these)
 ABI_SYMBOLS = [
     "jd_strerror", "jd_last_hip_error", "jd_init", "jd_shutdown", "jd_device_count", "jd_frame_check",
@@ -51,7 +56,7 @@ ABI_SYMBOLS = [
     "jd_batch_timing", "jd_batch_stage_times", "jd_batch_workspace_bytes", "jd_batch_unstuffed_len", "jd_parse", "jd_bmp_encode",
     "jd_batch_stage_reserve", "jd_batch_stage_ecs", "jd_batch_stage_jpegs", "jd_batch_submit", "jd_batch_host_rgb",
     "jd_host_alloc", "jd_host_free", "jd_decode_resident", "jd_parse_scans", "jd_decode_scans", "jd_decode_scans_coefficients",
-    "jd_decode_scans_batch",
+    "jd_decode_scans_batch", "jd_split_bands",
 ]
 
 
@@ -116,6 +121,7 @@ def _lib():
         L.jd_parse.argtypes = [_vp, _sz, PF, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
         L.jd_bmp_encode.argtypes = [_vp, _sz, _ci, _ci, _vp, _sz]
         L.jd_bmp_encode.restype = ctypes.c_long
+        L.jd_split_bands.argtypes = [PF, _vp, _sz, _ci, ctypes.POINTER(Band), ctypes.POINTER(_ci)]
         _LIB = L
     return _LIB
 
@@ -156,6 +162,16 @@ def parse(data):
     fr, off, ln = Frame(), _sz(), _sz()
     _check(_lib().jd_parse(a.ctypes.data, a.size, ctypes.byref(fr), ctypes.byref(off), ctypes.byref(ln)), "jd_parse")
     return fr, off.value, ln.value
+
+
+def split_bands(frame, ecs, parts):
+    """jd_split_bands: restart-interval-range sharding: cut a DRI image's stuffed segment into at most `parts`
+    bands of whole MCU rows.  -> [Band]; band k decodes like an image (frame = band.frame, segment =
+    ecs[band.ecs_off : band.ecs_off + band.ecs_len]) into pixel rows band.y0 .. band.y0 + band.frame.height."""
+    a = _as_u8(ecs)
+    bands, n = (Band * parts)(), _ci()
+    _check(_lib().jd_split_bands(ctypes.byref(frame), a.ctypes.data, a.size, parts, bands, ctypes.byref(n)), "jd_split_bands")
+    return [bands[i] for i in range(n.value)]
 
 
 def parse_scans(data, cap=64):
@@ -391,6 +407,12 @@ def shard_images(n_images, world, rank):
     if world < 1 or not 0 <= rank < world:
         raise ValueError("bad rank %d / world %d" % (rank, world))
     return list(range(rank, n_images, world))
+
+
+def shard_bands(n_bands, world, rank):
+    """Restart-interval-range sharding of ONE image: band k of split_bands goes to rank k % world, as
+    shard_images deals whole images.  The ranks write disjoint pixel rows of the picture; nothing is exchanged."""
+    return shard_images(n_bands, world, rank)
 
 
 def plan_job(total, world, rank, per_batch, distinct):

@@ -10,6 +10,7 @@
 // and unlike its ECS loop (main.go:993-1021) it does not copy or unstuff: it only finds where the segment
 // ends, keeping FF00 and RSTn in place for the device.
 #include <string.h>
+#include <vector>
 
 #include "../../include/jpeghip.h"
 
@@ -184,6 +185,64 @@ extern "C" int jd_parse_scans(const uint8_t* file, size_t file_len, jd_frame* fr
     if (!file || !fr || !scans || cap <= 0 || !n_scans) return JD_E_ARG;
     *n_scans = 0;
     return parse_impl(file, file_len, fr, scans, cap, n_scans, nullptr, nullptr);
+}
+
+// Restart-interval-range sharding: a restart interval starts with the DC predictors at zero
+// (main.go has no restart handling at all; T.81 E.2.4), so any run of whole intervals decodes on its own.  A band
+// is a run of whole MCU ROWS: then it is an image of its own -- same tables, same width, fewer rows -- and every entry
+// point of this library takes it as it is.
+extern "C" int jd_split_bands(const jd_frame* fr, const uint8_t* ecs, size_t ecs_len, int parts, jd_band* bands, int* n_bands) {
+    if (!fr || !ecs || !bands || !n_bands || parts < 1) return JD_E_ARG;
+    *n_bands = 0;
+    uint32_t mx = 0, my = 0, bpm = 0;
+    const int rc = jd_frame_geometry(fr, &mx, &my, &bpm);
+    if (rc != JD_OK) return rc;
+    const uint32_t ri = fr->restart_interval;
+    if (ri == 0 || mx % ri != 0) return JD_E_UNSUPPORTED;        // an MCU row must begin a restart interval
+    const uint32_t ipr = mx / ri;                                // intervals per MCU row
+    // RSTn numbers count modulo 8 from the start of the scan; a band's first marker must be RST0 again
+    uint32_t step = 8;
+    for (uint32_t g = ipr; step > 1 && g % 2 == 0; g /= 2) step /= 2;      // 8 / gcd(ipr, 8) rows
+    const uint32_t units = (my + step - 1) / step;               // band boundaries fall on multiples of `step` rows
+    const uint32_t nb = (uint32_t)parts < units ? (uint32_t)parts : units;
+    const uint32_t mcu_h = 8u * fr->comp[0].v;
+    // first MCU row of every band, then the byte ranges between the markers that separate them
+    std::vector<uint32_t> row0(nb + 1);
+    for (uint32_t k = 0; k <= nb; k++) {
+        const uint32_t r = (uint32_t)(((uint64_t)units * k / nb) * step);
+        row0[k] = r < my ? r : my;
+    }
+    std::vector<size_t> cut(nb + 1);                             // cut[k] = offset of band k's first byte
+    cut[0] = 0; cut[nb] = ecs_len;
+    uint32_t seen = 0, next = 1;                                 // markers seen; next band whose start is wanted
+    const uint8_t* p = ecs;
+    const uint8_t* const end = ecs + ecs_len;
+    while (next < nb && p < end) {
+        p = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
+        if (!p || p + 1 >= end) break;
+        const uint8_t m = p[1];
+        if (m >= 0xD0 && m <= 0xD7) {
+            if (m != 0xD0 + (seen & 7)) return JD_E_RESTART;
+            seen++;
+            while (next < nb && seen == row0[next] * ipr) {      // this marker ends the last interval before band `next`
+                cut[next] = (size_t)(p - ecs) + 2;
+                next++;
+            }
+            p += 2;
+        } else p += (m == 0xFF) ? 1 : 2;                         // FF00 stuffing, fill bytes; other markers are K0's to report
+    }
+    if (next < nb) return JD_E_RESTART;                          // fewer markers than the frame needs
+    for (uint32_t k = 0; k < nb; k++) {
+        jd_band& b = bands[k];
+        b.frame = *fr;
+        b.y0 = row0[k] * mcu_h;
+        const uint32_t y1 = row0[k + 1] * mcu_h < fr->height ? row0[k + 1] * mcu_h : fr->height;
+        b.frame.height = (uint16_t)(y1 - b.y0);
+        b.ecs_off = cut[k];
+        b.ecs_len = (k + 1 < nb ? cut[k + 1] - 2 : ecs_len) - cut[k];       // without the marker in front of the next band
+    }
+    *n_bands = (int)nb;
+    return JD_OK;
 }
 
 extern "C" long jd_bmp_encode(const uint8_t* rgb, size_t row_stride, int width, int height, uint8_t* out, size_t cap) {
