@@ -267,6 +267,7 @@ struct jd_batch {
     uint8_t* d_ecs_own = nullptr; uint8_t* d_rgb_own = nullptr; uint8_t* d_stream = nullptr;
     int16_t* d_coef = nullptr; uint16_t* d_lut = nullptr;
     uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
+    size_t clear_bytes = 0;                   // d_status .. d_changed + 64 words
     unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; JdSubPfx* d_subpfx = nullptr; JdSubCk* d_subck = nullptr; uint4* d_sync_tot = nullptr;
     uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr;
     // pinned host mirror of the descriptor block, followed by the read-back words (status per image, 64 sync flags)
@@ -355,11 +356,9 @@ const char* kStageNames[ST_COUNT_] = { "clear", "unstuff", "huffman_intervals", 
 // enqueue one stage (used by run and by profile)
 int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
     const JdKernelArgs a = kernel_args(b);
-    const int n = b->n;
     switch (stage) {
     case ST_CLEAR:
-        HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)n * sizeof(uint32_t), s));
-        HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(b->d_status, 0, b->clear_bytes, s));   // status words + changed flags
         break;
     case ST_UNSTUFF:
         jdk_launch_k0(a, b->d_pre_k0, b->wg_k0, s);
@@ -385,6 +384,11 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
     }
     HIPCHK(hipGetLastError());
     return JD_OK;
+}
+
+bool stage_is_empty(const jd_batch* b, int stage) {
+    return (stage == ST_HUFF_DRI && b->wg_iv == 0) || (stage == ST_HUFF_SYNC && b->wg_sync == 0) ||
+           (stage == ST_HUFF_WRITE && b->wg_wr == 0);
 }
 
 void batch_release(jd_batch* b) {
@@ -558,10 +562,12 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     A(&b->d_stream, stream);
     A(&b->d_coef, coef * sizeof(int16_t));
     A(&b->d_lut, lut_bytes);
-    A(&b->d_status, (size_t)n_images * 4);
+    // status words and the sync pass's "changed" flags sit in one block: one clear per run instead of two
+    b->clear_bytes = align_up((size_t)n_images * 4, 256) + 64 * 4;
+    A(&b->d_status, b->clear_bytes);
+    if (rc == JD_OK) b->d_changed = b->d_status + (b->clear_bytes - 64 * 4) / 4;
     A(&b->d_stream_len, (size_t)n_images * 4);
     A(&b->d_interval, (size_t)ivb * 4);
-    A(&b->d_changed, 64 * 4);
     A(&b->d_k0, ((size_t)k0c + 32) * 8);
     A(&b->d_ticket, ((size_t)n_images + 64) * 4);
     A(&b->d_sub, (size_t)subb * sizeof(JdSub));
@@ -642,7 +648,8 @@ int run_on(jd_batch* b, hipStream_t s) {
     if (timed) HIPCHK(hipEventRecord(ev[0], s));
     for (int st = 0; st < ST_COUNT_; st++) {
         int rc = enqueue_stage(b, st, s); if (rc) return rc;
-        if (timed) HIPCHK(hipEventRecord(ev[st + 1], s));
+        // (a stage with nothing to launch gets no event: an event costs a few microseconds of stream time)
+        if (timed && !stage_is_empty(b, st)) HIPCHK(hipEventRecord(ev[st + 1], s));
     }
     if (timed) b->timed_runs++;
     b->last_stream = s; b->ran = true;
@@ -798,7 +805,12 @@ extern "C" int jd_batch_stage_times(jd_batch* b, float* stage_us, const char** n
     std::vector<double> acc(ST_COUNT_, 0.0);
     for (int r = 0; r < b->timed_runs; r++) {
         hipEvent_t* ev = &b->events[(size_t)r * (ST_COUNT_ + 1)];
-        for (int st = 0; st < ST_COUNT_; st++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[st], ev[st + 1])); acc[st] += ms * 1000.0; }
+        hipEvent_t last = ev[0];
+        for (int st = 0; st < ST_COUNT_; st++) {
+            if (stage_is_empty(b, st)) continue;                 // no event was recorded for it: 0
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, last, ev[st + 1])); acc[st] += ms * 1000.0;
+            last = ev[st + 1];
+        }
     }
     for (int st = 0; st < ST_COUNT_; st++) { stage_us[st] = (float)(acc[st] / b->timed_runs); if (names) names[st] = kStageNames[st]; }
     const int n = b->timed_runs; b->timed_runs = 0;
@@ -879,7 +891,12 @@ extern "C" int jd_batch_profile(jd_batch* b, int iters, float* stage_us, const c
             HIPCHK(hipEventRecord(ev[st + 1], s));
         }
         HIPCHK(hipStreamSynchronize(s));
-        for (int st = 0; st < ST_COUNT_; st++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[st], ev[st + 1])); acc[st] += ms * 1000.0; }
+        hipEvent_t last = ev[0];
+        for (int st = 0; st < ST_COUNT_; st++) {
+            if (stage_is_empty(b, st)) continue;                 // no event was recorded for it: 0
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, last, ev[st + 1])); acc[st] += ms * 1000.0;
+            last = ev[st + 1];
+        }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     for (int st = 0; st < ST_COUNT_; st++) { stage_us[st] = (float)(acc[st] / iters); if (names) names[st] = kStageNames[st]; }
