@@ -36,6 +36,7 @@
 #define JD_W32_DC_BITS 9
 #define JD_W32_AC_BITS_WIDE 10
 #define JD_W32_AC_BITS_NARROW 9
+#define JD_W32_NONE 0x80000000u     // no such code (a secondary-table pointer with offset 0)
 #define JD_W32_EOB_ADV 254u
 #define JD_W32_EOB_ADV8 127u        // byte form (write_segments8): the advance counts coefficients, not bytes
 

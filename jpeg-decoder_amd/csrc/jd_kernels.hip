@@ -737,7 +737,10 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     auto ring_at = [&](uint32_t xb) { return la_u32(ring_b | (xb & 63u)); };
     uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 4), nxt = ring_at(rpb + 8);
     rpb += 12;
-    uint32_t sh = 32u - o0;
+    // `sh` (how far the window's first bit sits below the top of w0) is kept with every bit above its five set: a
+    // shift operand reads the low five anyway, and adding an entry's 32 - bits then CARRIES exactly when the window
+    // stays in w0 -- v_add_co gives the new count and the select mask in one instruction (no separate compare)
+    uint32_t sh = (32u - o0) | ~31u;
     uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;
     uint32_t npend = 0;
 
@@ -795,11 +798,11 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         wave_lds_order();
     };
     auto advance = [&](uint32_t e, uint32_t cand) {
-        const uint32_t t = sh + (e & 31u);
-        const bool r = t < 32u;
-        sh = t & 31u;
-        w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
-        rpb += r ? four : 0u;
+        uint32_t t;
+        const bool stay = __builtin_add_overflow(sh, e & 31u, &t);
+        sh = t | ~31u;
+        w0 = stay ? w0 : w1; w1 = stay ? w1 : nxt; nxt = stay ? nxt : cand;
+        rpb += stay ? 0u : four;
     };
     auto flush = [&](uint32_t st) {
 #pragma unroll
@@ -886,7 +889,7 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         uint32_t o = idle, e = 0, wl0 = 0, wl1 = 0, wcnt = 0, dchi = 0;
         bool wide_dc = false;
         int dcv = 0;
-        const uint32_t rpb0 = rpb, sh0 = sh;                              // where this block starts (for wide_block)
+        const uint32_t rpb0 = rpb, sh0 = sh & 31u;                        // where this block starts (for wide_block)
         if (act) {
             if (__builtin_amdgcn_ballot_w64(rpb >= wqb)) top_up_now();
             const uint32_t cand = ring_at(rpb);
@@ -903,22 +906,36 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             dcv = pred;
             o = 0;
         }
+        int v = 0;
         while (o < 63u) {                                                 // divergent loop: finished lanes drop out
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
             const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
-            e = w32_lookup(acb, win, ac_bits, bad);
-            const int v = w32_value(win, e);
+            e = la_u32(acb + ((win >> (30u - ac_bits)) & (((1u << ac_bits) - 1u) << 2)));
+            // ONE test for everything rare: a secondary-table pointer and "no such code" have bit 31 set (jd_tables.cpp),
+            // an entry of magnitude category >= 8 has bit 23 of its mask field set
+            if (__builtin_expect(e >= (1u << 23), 0)) {
+                if ((int)e < 0) {
+                    const uint32_t so = e & 0x7FFFFFFFu;
+                    e = so ? la_u32(acb + (so << 2) + ((win >> 14) & ((0xFFFFu >> ac_bits) << 2))) : JD_W32_NONE;
+                    if ((int)e < 0) { bad = 1; e = JD_W32_SKIP; }
+                }
+                if (e >= (1u << 23)) {                                    // keep the high part (the low byte is stored below)
+                    const int wv = w32_value(win, e);
+                    const uint32_t wo = o + ((e >> 8) & 255u);
+                    wl1 = (wl1 << 16) | (wl0 >> 16);
+                    wl0 = (wl0 << 16) | ((wo & 255u) << 8) | (((uint32_t)(wv - (int)(int8_t)wv) >> 8) & 0xFFu);
+                    wcnt++;
+                }
+            }
+            v = w32_value(win, e);
             advance(e, cand);
             o += (e >> 8) & 255u;
-            const uint32_t at = o < 64u ? slot_b + (o ^ rot) : dump_b;
-            la_st8(at, v);
-            if (__builtin_expect(e >= (1u << 23), 0)) {                  // magnitude category >= 8: keep the high part
-                wl1 = (wl1 << 16) | (wl0 >> 16);
-                wl0 = (wl0 << 16) | ((o & 255u) << 8) | (((uint32_t)(v - (int)(int8_t)v) >> 8) & 0xFFu);
-                wcnt++;
-            }
+            // only the lanes that stay in the loop store here (their index is inside the block: no range test, no dump
+            // byte); the symbol that ENDS a block by filling coefficient 63 is stored below, once
+            if (o < 63u) la_st8(slot_b + (o ^ rot), v);
         }
+        if (o == 63u) la_st8(slot_b + (63u ^ rot), v);
         if (act) {
             // a block ends at index 63 exactly or by EOB (>= 127); in between = a run that walked past coefficient 63
             if (o > 63u && o < 127u) err |= JD_ST_COEF;
@@ -945,7 +962,7 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     if (sg.nblk) {
         if (bad) err |= JD_ST_HUFF;
         const uint32_t rp = (rpb - rot) >> 2;
-        const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - sh);
+        const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - (sh & 31u));
         if (pos > sg.end_bit) err |= JD_ST_TRUNC;
     }
     if (err) atomicOr(&a.status[img], err);

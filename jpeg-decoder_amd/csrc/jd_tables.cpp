@@ -157,6 +157,9 @@ int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool i
         }
         code <<= 1;
     }
+    // "no such code" is a secondary-table pointer to nowhere: every entry the decode loop must look at twice (secondary
+    // table, no code, magnitude category >= 8) is then >= 2^23 as an unsigned number -- one compare per symbol
+    for (size_t i = base; i < out.size(); i++) if (out[i] == 0) out[i] = JD_W32_NONE;
     return 0;
 }
 

@@ -38,7 +38,7 @@ static uint16_t look16(const std::vector<uint16_t>& t, uint32_t win, unsigned lu
 static uint32_t look32(const std::vector<uint32_t>& t, uint32_t win, unsigned pb) {
     uint32_t e = t[win >> (32 - pb)];
     if (e & 0x80000000u) e = (e & 0x7FFFFFFFu) ? t[(e & 0x7FFFFFFFu) + ((win >> 16) & (0xFFFFu >> pb))] : 0;
-    return e;
+    return e == JD_W32_NONE ? 0 : e;                              // "no such code" (jd_tables.cpp)
 }
 
 static void check_table(const char* name, const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc) {
