@@ -242,3 +242,33 @@ func decodeScansOnGPU(header *Header, scans []C.jd_scan, file []byte) []byte {
 	}
 	return rgb
 }
+
+// Restart-interval-range sharding (SURVEY 8e(ii)): one DRI picture over several GPUs.  Each band of jd_split_bands is an
+// image of its own; device k decodes band k (one goroutine / OS thread per device) straight into its rows of the picture.
+func decodeBandsOnGPUs(header *Header, rawECS []byte, devices int) []byte {
+	f := frameFromHeader(header)
+	bands := make([]C.jd_band, devices)
+	var n C.int
+	if rc := C.jd_split_bands(&f, (*C.uint8_t)(unsafe.Pointer(&rawECS[0])), C.size_t(len(rawECS)), C.int(devices), &bands[0], &n); rc != 0 {
+		return decodeOnGPU(header, rawECS) // no restart markers at the MCU-row starts: the whole picture on one device
+	}
+	stride := int(header.width) * 3
+	rgb := make([]byte, stride*int(header.height))
+	done := make(chan C.int, int(n))
+	for k := 0; k < int(n); k++ {
+		go func(k int) {
+			b := &bands[k]
+			seg := rawECS[int(b.ecs_off) : int(b.ecs_off)+int(b.ecs_len)]
+			rows := rgb[int(b.y0)*stride:]
+			done <- C.jd_decode(&b.frame, (*C.uint8_t)(unsafe.Pointer(&seg[0])), C.size_t(len(seg)), 1, nil, 0,
+				(*C.uint8_t)(unsafe.Pointer(&rows[0])), C.size_t(stride), C.int(k))
+		}(k)
+	}
+	for k := 0; k < int(n); k++ {
+		if rc := <-done; rc != 0 {
+			fmt.Printf("%s\n", C.GoString(C.jd_strerror(rc)))
+			os.Exit(1)
+		}
+	}
+	return rgb
+}
