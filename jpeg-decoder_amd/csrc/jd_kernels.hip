@@ -431,6 +431,7 @@ __device__ __forceinline__ uint32_t lut_lookup(uint32_t tb, uint32_t win, uint32
 typedef __attribute__((address_space(3))) uint8_t* jd_lds_ptr;
 __device__ __forceinline__ uint32_t lds_abs_base() { return (uint32_t)(uintptr_t)(jd_lds_ptr)dyn_lds; }
 __device__ __forceinline__ uint32_t la_u32(uint32_t addr) { return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)addr; }
+__device__ __forceinline__ uint32_t la_u16(uint32_t addr) { return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)addr; }
 __device__ __forceinline__ uint4 la_u4(uint32_t addr) {
     const jd_u32x4 v = *(__attribute__((address_space(3))) const jd_u32x4*)(uintptr_t)addr;
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -1086,12 +1087,17 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     top_up();
     uint32_t w0 = ring_at(rpb), w1 = ring_at(rpb + 256u), nxt = ring_at(rpb + 512u);
     rpb += 768u;
-    int sh = 32 - (int)o0;
+    uint32_t sh = 32u - o0;
     int left = run ? (int)(end - start) : 0;                              // bits of the sub-sequence still to decode
     uint32_t c = (entry >> 8) & 0xFFu, z = (entry >> 16) & 0x7Fu;
     if (c >= ik.bpm) c = 0;
     uint32_t t = lds_u32(JD_SY_CTAB + c * 4u);
-    uint32_t dcb = (t & 0x7FFFu) << 2, acb = ((t >> 15) & 0x7FFFu) << 2, csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
+    // table bases as absolute LDS addresses, and the one the NEXT symbol reads kept in a register of its own (switched
+    // where a block starts and where its DC symbol has been read: both rare paths run anyway) -- no select, no base
+    // addition in the per-symbol path
+    const uint32_t lut0 = lds_abs_base();
+    uint32_t dcb = lut0 + ((t & 0x7FFFu) << 2), acb = lut0 + (((t >> 15) & 0x7FFFu) << 2), csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
+    uint32_t tb = z ? acb : dcb;
     uint32_t nstart = 0, first = 0;
     *lds_int(dcs_l) = 0; *lds_int(dcs_l + JD_SYNC_WG * 4u) = 0; *lds_int(dcs_l + 2u * JD_SYNC_WG * 4u) = 0;
     wave_lds_order();
@@ -1111,12 +1117,11 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     while (left > 0) {
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up();
         const uint32_t cand = ring_at(rpb);
-        const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
-        const uint32_t tb = z ? acb : dcb;
-        uint32_t e = lds_u16(tb + ((win >> (32 - JD_SLUT_BITS)) << 1));
+        const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
+        uint32_t e = la_u16(tb + ((win >> (32 - JD_SLUT_BITS)) << 1));
         if (__builtin_expect((e & 0x8000u) != 0 || e == 0, 0)) {
             const uint32_t o = e & 0x7FFFu;
-            e = (e && o) ? lds_u16(tb + (o << 1) + (((win >> (32 - JD_SLUT_BITS - 6)) & 63u) << 1)) : 0u;
+            e = (e && o) ? la_u16(tb + (o << 1) + (((win >> (32 - JD_SLUT_BITS - 6)) & 63u) << 1)) : 0u;
             if (e == 0) e = 1;                                            // speculative: step over one bit
         }
         uint32_t total = e & 31u;
@@ -1149,6 +1154,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
                 atomicAdd(lds_int(csum), extend_bits(win, total, (e >> 5) & 15u));   // ds_add, no return
             }
             zn = 1;
+            tb = acb;
         } else if (zn >= 64u) {
             // the block ends in this group: fine if it ends with the group (index 64 reached by its last symbol, or
             // EOB before index 64); if the block filled up INSIDE the group, the rest of the group belongs to the
@@ -1163,16 +1169,19 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
                 zn = z + ((e1 >> 9) & 63u) + 1u;
             }
         }
-        sh -= (int)total; left -= (int)total;
-        const bool r = sh < 0;
+        // sh - total borrows exactly when the window moves past w0 (v_sub_co: the new count and the select mask at once)
+        uint32_t sh2;
+        const bool r = __builtin_sub_overflow(sh, total, &sh2);
+        sh = sh2 & 31u; left -= (int)total;
         w0 = r ? w1 : w0; w1 = r ? nxt : w1; nxt = r ? cand : nxt;
-        sh += r ? 32 : 0; rpb += r ? 256u : 0u;
+        rpb += r ? 256u : 0u;
         z = zn;
         if (z >= 64u) {                                                   // block complete: next block's tables
             z = 0;
             c = (c + 1u == ik.bpm) ? 0u : c + 1u;
             t = lds_u32(JD_SY_CTAB + c * 4u);
-            dcb = (t & 0x7FFFu) << 2; acb = ((t >> 15) & 0x7FFFu) << 2; csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
+            dcb = lut0 + ((t & 0x7FFFu) << 2); acb = lut0 + (((t >> 15) & 0x7FFFu) << 2); csum = dcs_l + ((t >> 30) * (JD_SYNC_WG * 4u));
+            tb = dcb;
         }
     }
     wave_lds_order();
