@@ -5,7 +5,7 @@ import numpy as np
 import jpeg_decoder_amd as jd, orclib
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 90.0
-t0 = time.time(); n = 0; bad = 0
+t0 = time.time(); n = 0; bad = 0; t_say = t0
 modes = [(1, 1, 1), (1, 1, 3), (2, 1, 3), (1, 2, 3), (2, 2, 3)]
 while time.time() - t0 < budget:
     hs, vs, nc = rng.choice(modes)
@@ -27,6 +27,8 @@ while time.time() - t0 < budget:
     except Exception as e:
         ok = False; print("EXC", e)
     n += 1
+    if time.time() - t_say > 30:                      # (a silent GPU command is taken to be hung)
+        t_say = time.time(); print("...", n, "cases,", bad, "bad", flush=True)
     if not ok:
         bad += 1; print("MISMATCH", w, h, hs, vs, nc, q, detail, ri, form, flags)
 print("cases", n, "bad", bad)
