@@ -1788,8 +1788,12 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     };
     fetch(0);
 
+    // (grey: one block per lane.  Left as straight-line code hipcc needs more than 256 registers for it -- it fits the
+    // six-block loop of 4:2:0 into 218 -- so the trip count is hidden from it)
+    uint32_t n_steps = BPM;
+    if constexpr (NC == 1) asm volatile("" : "+s"(n_steps));
 #pragma unroll 1
-    for (uint32_t st = 0; st < BPM; st++) {
+    for (uint32_t st = 0; st < n_steps; st++) {
         const uint32_t b = __builtin_amdgcn_readfirstlane(block_of(st));
         const uint32_t comp = b < NL ? 0u : b - NL + 1u;
         // the quantisation table is wave-uniform: read through the constant address space so that it IS a scalar load
@@ -1832,7 +1836,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 asm volatile("" : "+v"(hw[8]), "+v"(hw[9]), "+v"(hw[10]), "+v"(hw[11]), "+v"(hw[12]), "+v"(hw[13]), "+v"(hw[14]), "+v"(hw[15]));
             }
         }
-        if (st + 1u < BPM) fetch(st + 1u);
+        if (st + 1u < n_steps) fetch(st + 1u);
         // column pass; its outputs are truncated to int as the reference does (main.go:521-528).  (Keeping them in fp64
         // with trunc() would save the 64 conversions back, but 128 registers of intermediates spill: 162 VGPRs spilled.)
         int mid[64];
@@ -2156,10 +2160,12 @@ void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uin
                             hipStream_t s) {
     JdKernelArgs x = a; x.prefix = d_prefix;
     if (!wgs) return;
-    const uint32_t lds = 8192 + 8 * 1536;
+    // dynamic LDS per wave: 8 KiB for the coefficient DMA; the modes with two luma blocks side by side (2 and 4) also park
+    // the left block's pixel rows (8 x 1536 B) -- the others must not pay for that in occupancy
 #define JD_K2_LAUNCH(M) \
-    if (modes & (1u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, false>), dim3(wgs), dim3(64), lds, s, x, K); \
-    if (modes & (2u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, true>), dim3(wgs), dim3(64), lds, s, x, K);
+    { const uint32_t lds = 8192u + ((M) == 2 || (M) == 4 ? 8u * 1536u : 0u); \
+      if (modes & (1u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, false>), dim3(wgs), dim3(64), lds, s, x, K); \
+      if (modes & (2u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, true>), dim3(wgs), dim3(64), lds, s, x, K); }
     JD_K2_LAUNCH(0) JD_K2_LAUNCH(1) JD_K2_LAUNCH(2) JD_K2_LAUNCH(3) JD_K2_LAUNCH(4)
 #undef JD_K2_LAUNCH
 }
