@@ -1907,6 +1907,17 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                     if (b == NL) chroma[0][i * 4 + k] = p.u; else chroma[1][i * 4 + k] = p.u;
                 }
             }
+            // VS = 1: the luma blocks only read chroma rows 0-3, hipcc drops the other four row passes -- and
+            // then allocates the 4:2:2 kernel so badly that it spills 47 registers (K2 + 35 %).  Kept "in use", the kernel
+            // has the shape of the 4:2:0 one, which fits: four wasted row passes per chroma block are the cheaper evil.
+            if constexpr (VS == 1 && HS == 2) {
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int i = 16; i < 32; i += 8)
+                        asm volatile("" :: "v"(chroma[c][i]), "v"(chroma[c][i + 1]), "v"(chroma[c][i + 2]), "v"(chroma[c][i + 3]),
+                                     "v"(chroma[c][i + 4]), "v"(chroma[c][i + 5]), "v"(chroma[c][i + 6]), "v"(chroma[c][i + 7]));
+            }
             continue;
         }
         // chroma quadrant of this luma block: rows by*4 .. by*4+3, columns bx*4 .. bx*4+3
