@@ -915,7 +915,7 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             e = la_u32(acb + ((win >> (30u - ac_bits)) & (((1u << ac_bits) - 1u) << 2)));
             // ONE test for everything rare: a secondary-table pointer and "no such code" have bit 31 set (jd_tables.cpp),
             // an entry of magnitude category >= 8 has bit 23 of its mask field set
-            if (__builtin_expect(e >= (1u << 23), 0)) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(e >= (1u << 23)) != 0, 0) && e >= (1u << 23)) {   // (one wave-wide branch in the common case)
                 if ((int)e < 0) {
                     const uint32_t so = e & 0x7FFFFFFFu;
                     e = so ? la_u32(acb + (so << 2) + ((win >> 14) & ((0xFFFFu >> ac_bits) << 2))) : JD_W32_NONE;
