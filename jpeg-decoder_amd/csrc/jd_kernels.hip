@@ -1119,7 +1119,8 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
         const uint32_t cand = ring_at(rpb);
         const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
         uint32_t e = la_u16(tb + ((win >> (32 - JD_SLUT_BITS)) << 1));
-        if (__builtin_expect((e & 0x8000u) != 0 || e == 0, 0)) {
+        const bool special = (e & 0x8000u) != 0 || e == 0;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0) && special) {   // (one wave-wide branch in the common case)
             const uint32_t o = e & 0x7FFFu;
             e = (e && o) ? la_u16(tb + (o << 1) + (((win >> (32 - JD_SLUT_BITS - 6)) & 63u) << 1)) : 0u;
             if (e == 0) e = 1;                                            // speculative: step over one bit
