@@ -141,7 +141,9 @@ struct JdSub {
 // every fifth of the sub-sequence (state and running counts) plus its totals and exit state -- one self-consistent trajectory.  A later decode of the same
 // sub-sequence from a corrected entry state stops at the first checkpoint whose state it reproduces (from there on it IS
 // that trajectory) and takes the rest of the counts from the record.
+#ifndef JD_CK_N
 #define JD_CK_N 4
+#endif
 struct JdCkEntry {               // 32 bytes: written with two 16-byte non-temporal stores, never in parts
     uint32_t state;              // bits left << 12 | block-in-MCU << 8 | zig-zag index (0 = no checkpoint); totals: exit state
     uint32_t nstart;             // blocks started so far (totals: in the whole sub-sequence)
