@@ -224,7 +224,7 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     if (threadIdx.x == 0) __hip_atomic_store(st, mine | (chunk ? JD_K0_AGG : JD_K0_PFX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Compaction: a dword's kept bytes are squeezed to its low end by one v_perm (selector from a 16-entry table) and
     // the dword is stored at its BYTE offset in the compacted chunk (LDS takes unaligned dword writes on gfx950:
-    // exp/lds_unaligned.hip).  The bytes above the kept ones are rubbish; the lane's next dword overwrites them (same
+    // profiles/microbench/lds_unaligned.hip).  The bytes above the kept ones are rubbish; the lane's next dword overwrites them (same
     // wave, LDS executes in order).  A dword whose rubbish would reach past the lane's last kept byte -- into bytes the
     // next lane wrote in an EARLIER instruction -- is written byte by byte instead: only ever one of the lane's last
     // dwords, and only when fewer than four kept bytes follow its first.
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(JD_K0_THREADS, JD_K0_WAVES_PER_SIMD) void k0_unstuf
     uint8_t* dst = a.stream + stream_off + JD_STREAM_FRONT + (base.x - al);   // 16-byte aligned
     const uint32_t lo = al, hi = al + tk;                        // valid byte range of the window
     const uint32_t qlo = (lo + 15u) >> 4, qhi = hi >> 4;         // whole quads [qlo, qhi)
-    // (LDS takes a 16-byte read at any byte address on gfx950 -- exp/lds_unaligned128.hip; through asm, so that the
+    // (LDS takes a 16-byte read at any byte address on gfx950 -- profiles/microbench/lds_unaligned128.hip; through asm, so that the
     // reads of both rounds are in flight together)
     const uint32_t src_b = (uint32_t)(uintptr_t)buf - al;
     static_assert(JD_K0_CHUNK / 16 + 1 <= 3 * JD_K0_THREADS, "copy-out rounds");
