@@ -281,7 +281,7 @@ def main():
             "metric": "decoded megapixels/sec", "value": round(n_job * w * h / (dt / args.steps) / 1e6, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "strong" if wl == "c5" else "weak", "vs_baseline": None,
-            "dtype": "f64 IDCT / f32 colour / int16 coefficients", "data": "synthetic",
+            "dtype": "f64 IDCT / f32 colour / int16 coefficients (bytes between the kernels)", "data": "synthetic",
             "config": {"workload": LABEL[wl], "mode": {"resident": "(i) inputs and outputs resident in HBM",
                                                        "e2e": "(ii) pinned host -> H2D -> kernels -> D2H -> pinned host, 3 batches in flight",
                                                        "host": "(iii) as (ii) + header parsing and ECS staging from whole files"}[args.mode],
