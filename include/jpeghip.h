@@ -175,8 +175,8 @@ int jd_host_alloc(size_t bytes, void** out);
 void jd_host_free(void* p);
 
 /* ---- allocation-free decode ------------------------------------------------------------------------
- * No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  The same decode as
+ * No counterpart in the reference.  For callers that cannot allocate device memory: serving loops and harnesses
+ * that forbid hipMalloc (or run with the device's memory already handed out).  The same decode as
  * jd_batch_{create, bind_ecs, bind_rgb, run, wait} for one image, but the whole workspace (descriptors,
  * tables, unstuffed stream, restart index, sync records, coefficients) lives in a file-scope device array of
  * the library (12 MiB per device, held until the process ends) whose address jd_init looked up per device:
@@ -185,7 +185,11 @@ void jd_host_free(void* p);
  *   d_rgb    DEVICE memory: height rows of row_stride bytes (as jd_batch_bind_rgb)
  *   limits   ecs_len <= JD_RESIDENT_MAX_ECS and MCUs x blocks-per-MCU x 64 <= JD_RESIDENT_MAX_COEF
  *            (1920 x 1080 4:2:0 fits; up to 2.7 MP 4:2:0 or 1.39 MP 4:4:4), else JD_E_TOO_LARGE
- * Enqueues on hip_stream (NULL = a stream of the library's) and returns when the pixels are in d_rgb.
+ * SYNCHRONOUS: enqueues on hip_stream (NULL = a stream of the library's), waits for that stream and reads the
+ * per-image status back before it returns (pixels are then in d_rgb) -- so it must not be called while hip_stream
+ * is being captured into a graph.  Allocation-free means the device / HIP side: the first call for a frame plans
+ * on the host (table packing, a few small host allocations); repeated calls with the same jd_frame reuse that plan
+ * and do no host allocation either.
  * Calls on one device share that device's array: the library serialises them on the host, so they never
  * overlap; two PROCESSES are independent (each has its own copy). */
 #define JD_RESIDENT_MAX_ECS (2u << 20)

@@ -60,6 +60,11 @@ struct DevCtx {
     uint8_t* pinned = nullptr; size_t pinned_bytes = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;                            // host-side: one jd_decode_resident at a time per device
+    // the plan of the last jd_decode_resident on this device (descriptors, packed tables already in the scratch): a call
+    // with the same frame and an entropy-coded segment that fits its capacity skips the planning and the table upload
+    ::jd_batch* plan = nullptr;
+    jd_frame plan_frame;
+    size_t plan_cap = 0;
 };
 const size_t kStaticPinnedBytes = 1u << 20;
 
@@ -74,9 +79,12 @@ DevCtx* find_ctx(int device) {
     return nullptr;
 }
 
+void drop_plan(DevCtx* c);
+
 void release_ctx_locked() {
     for (auto& c : g_ctx) {
         if (hipSetDevice(c->device) != hipSuccess) continue;
+        drop_plan(c.get());
         if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
         if (c->pinned) (void)hipHostFree(c->pinned);
     }
@@ -141,7 +149,8 @@ extern "C" const char* jd_strerror(int code) {
     switch (code) {
     case JD_OK: return "ok";
     case JD_E_ARG: return "invalid argument";
-    case JD_E_UNSUPPORTED: return "Error! unsupported frame (baseline, 1 or 3 components, luma 1-2 x 1-2, chroma 1x1 only)";
+    case JD_E_UNSUPPORTED: return "Error! unsupported frame (8-bit, 1 or 3 components -- the reference's loops would take 2, main.go:112-115, "
+                                  "but no encoder writes such files and no kernel is built for them --, luma 1-2 x 1-2, chroma 1x1; scans of 1-3 components)";
     case JD_E_TABLE: return "Error! missing or malformed quantisation / Huffman table";
     case JD_E_HIP: return "HIP runtime error";
     case JD_E_NOMEM: return "out of memory";
@@ -1035,6 +1044,15 @@ extern "C" int jd_decode_coefficients(const jd_frame* frame, const uint8_t* ecs,
 // (the array's address, the pinned block and the stream were set up per device by jd_init).  Calls on one device share
 // that device's array: they are serialised on the host by a mutex, and each call clears what must start at zero (stream
 // pads, status and sync flags, K0 tickets and look-back words) on the stream before its kernels.
+namespace {
+void drop_plan(DevCtx* c) {
+    if (!c->plan) return;
+    if (c->plan->last_stream) (void)hipStreamSynchronize(c->plan->last_stream);
+    batch_release(c->plan);
+    c->plan = nullptr; c->plan_cap = 0;
+}
+}  // namespace
+
 extern "C" int jd_decode_resident(const jd_frame* frame, const void* d_ecs, size_t ecs_len, void* d_rgb, size_t row_stride,
                                   int device, void* hip_stream) {
     if (!frame || !d_ecs || !d_rgb || ecs_len == 0) return JD_E_ARG;
@@ -1044,16 +1062,32 @@ extern "C" int jd_decode_resident(const jd_frame* frame, const void* d_ecs, size
     if (rc) return rc;
     if (ecs_len > JD_RESIDENT_MAX_ECS || (uint64_t)g.mcux * g.mcuy * g.bpm * 64 > JD_RESIDENT_MAX_COEF) return JD_E_TOO_LARGE;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    jd_batch* b = nullptr;
-    rc = batch_build(device, 1, frame, &ecs_len, 0, ctx, s, &b);
-    if (rc) return rc;
+    // Repeated calls with one frame (a serving loop on one camera / one encoder setting) reuse the plan: no table
+    // packing, no host allocation, no table upload.  Anything else plans afresh (host work only; the device side
+    // is the same fixed array either way).
+    if (ctx->plan && (memcmp(&ctx->plan_frame, frame, sizeof *frame) != 0 || ecs_len > ctx->plan_cap)) drop_plan(ctx);
+    if (!ctx->plan) {
+        size_t cap = std::min<size_t>(JD_RESIDENT_MAX_ECS, align_up(ecs_len + ecs_len / 4, 65536));   // room for the next, larger one
+        jd_batch* nb = nullptr;
+        rc = batch_build(device, 1, frame, &cap, 0, ctx, s, &nb);
+        if (rc == JD_E_TOO_LARGE && cap != ecs_len) { cap = ecs_len; rc = batch_build(device, 1, frame, &cap, 0, ctx, s, &nb); }
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }   // (a table upload may already be in flight from the pinned block)
+        ctx->plan = nb; ctx->plan_frame = *frame; ctx->plan_cap = cap;
+    }
+    jd_batch* b = ctx->plan;
+    b->stream = s;
     rc = jd_batch_bind_ecs(b, 0, d_ecs, ecs_len);
     if (!rc) rc = jd_batch_bind_rgb(b, 0, d_rgb, row_stride);
     if (!rc) rc = run_on(b, s);
     if (!rc) rc = wait_on(b);
-    else (void)hipStreamSynchronize(s);                      // nothing of this call may still read the shared blocks
-    batch_release(b);
+    if (rc == JD_E_HIP || rc == JD_E_STATE || rc == JD_E_ARG) {
+        // not a verdict on the image: something may still be in flight on `s` that reads the shared scratch and the
+        // pinned block -- drain it before the lock is released, and do not trust the plan any more
+        (void)hipStreamSynchronize(s);
+        drop_plan(ctx);
+    }
     return rc;
 }
 

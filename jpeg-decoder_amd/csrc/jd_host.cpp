@@ -124,7 +124,8 @@ static int parse_impl(const uint8_t* file, size_t file_len, jd_frame* fr, jd_sca
             if (!have_sof) return JD_E_MARKER;
             if (r.i >= end) return JD_E_TRUNCATED;                                // empty SOS payload: nothing to read
             const int ns = r.u8();
-            if (ns < 1 || ns > 3 || r.i + (size_t)ns * 2 + 3 > end) return JD_E_TRUNCATED;
+            if (ns < 1 || ns > 3) return JD_E_UNSUPPORTED;                        // a scan of 0 or > 3 components is not truncation
+            if (r.i + (size_t)ns * 2 + 3 > end) return JD_E_TRUNCATED;
             jd_scan local; jd_scan* sc = &local;
             if (scans) { if (ns_found >= cap) return JD_E_ARG; sc = &scans[ns_found]; }
             memset(sc, 0, sizeof *sc);
@@ -205,7 +206,8 @@ extern "C" int jd_split_bands(const jd_frame* fr, const uint8_t* ecs, size_t ecs
     for (uint32_t g = ipr; step > 1 && g % 2 == 0; g /= 2) step /= 2;      // 8 / gcd(ipr, 8) rows
     const uint32_t units = (my + step - 1) / step;               // band boundaries fall on multiples of `step` rows
     const uint32_t nb = (uint32_t)parts < units ? (uint32_t)parts : units;
-    const uint32_t mcu_h = 8u * fr->comp[0].v;
+    // (a single-component frame has a 1x1 MCU whatever its SOF sampling byte says: frame_geometry, main.go:753-767)
+    const uint32_t mcu_h = 8u * (fr->ncomp == 1 ? 1u : fr->comp[0].v);
     // first MCU row of every band, then the byte ranges between the markers that separate them
     std::vector<uint32_t> row0(nb + 1);
     for (uint32_t k = 0; k <= nb; k++) {

