@@ -116,6 +116,7 @@ int status_to_error(uint32_t st) {
     if (st & JD_ST_COEF) return JD_E_COEF;
     if (st & JD_ST_TRUNC) return JD_E_TRUNCATED;
     if (st & (JD_ST_SYNC | JD_ST_COUNT)) return JD_E_SYNC;
+    if (st & JD_ST_SAMPLE) return JD_E_COEF;
     return JD_OK;
 }
 
@@ -157,7 +158,7 @@ extern "C" const char* jd_strerror(int code) {
     case JD_E_MARKER: return "Invalid marker found in the bitsteam";
     case JD_E_RESTART: return "Error! restart markers do not match the restart interval";
     case JD_E_HUFFMAN: return "Error! invalid DC Symbols";
-    case JD_E_COEF: return "Error! run/size walks past coefficient 63, or a coefficient leaves 16 bits (AC 63 in the byte form: 12 bits)";
+    case JD_E_COEF: return "Error! run/size walks past coefficient 63, or a coefficient (AC 63 in the byte form: 12 bits) or a chroma sample leaves 16 bits";
     case JD_E_TRUNCATED: return "Error! EOF";
     case JD_E_SYNC: return "internal error: self-synchronising decode did not converge";
     case JD_E_NOT_INIT: return "jd_init has not been called or found no device";

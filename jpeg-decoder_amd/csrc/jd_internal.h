@@ -84,7 +84,9 @@ enum {
     JD_ST_COEF = 1u << 4,        // coefficient index ran past 63
     JD_ST_TRUNC = 1u << 5,       // data ended early / interval overrun
     JD_ST_SYNC = 1u << 6,        // sync result inconsistent
-    JD_ST_COUNT = 1u << 7        // decoded block count != expected
+    JD_ST_COUNT = 1u << 7,       // decoded block count != expected
+    JD_ST_SAMPLE = 1u << 8       // a post-IDCT chroma sample left int16 (K2; reported last: a damaged stream that
+                                 // already earned another bit usually decodes to such garbage as well)
 };
 
 enum {

@@ -1897,7 +1897,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
         };
         if (b >= NL) {                                             // wave-uniform: a chroma block's samples wait in registers
             int smax = 0, smin = 0;                                // as int16 pairs (exact for every stream an 8-bit encoder
-#pragma unroll                                                     // can make; a sample outside int16 raises JD_ST_COEF below)
+#pragma unroll                                                     // can make; a sample outside int16 raises JD_ST_SAMPLE below)
             for (int i = 0; i < 8; i++) {
                 int o[8];
                 row_pass(i, o);
@@ -1916,7 +1916,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
             // has the shape of the 4:2:0 one, which fits: four wasted row passes per chroma block are the cheaper evil.
             // only a crafted stream gets here (|sample| of an 8-bit encoder's data stays below ~1100): the packing above
             // saturated, so the pixels would differ from the reference's -- say so instead
-            if (__builtin_expect(smax > 32767 || smin < -32768, 0)) atomicOr(&a.status[img], (uint32_t)JD_ST_COEF);
+            if (__builtin_expect(smax > 32767 || smin < -32768, 0)) atomicOr(&a.status[img], (uint32_t)JD_ST_SAMPLE);
             if constexpr (VS == 1 && HS == 2) {
 #pragma unroll
                 for (int c = 0; c < 2; c++)
