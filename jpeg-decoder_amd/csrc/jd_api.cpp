@@ -34,7 +34,7 @@ void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, i
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K, hipStream_t s);
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
-                      const uint32_t* d_plut, uint32_t max_lut_bytes, hipStream_t s);
+                      const uint32_t* d_plut, const uint32_t* d_plen, const uint32_t* d_pstatus, hipStream_t s);
 int jdk_static_scratch(void** ptr, size_t* bytes);
 }
 
@@ -1093,9 +1093,11 @@ extern "C" int jd_decode_resident(const jd_frame* frame, const void* d_ecs, size
 }
 
 // ---- progressive files ---------------------------------------------------------------------
-// Host side of jd_decode_scans: unstuff every scan the way main.go:993-1021 does (FF00 -> FF, RSTn dropped -- the
-// reference never acts on restart markers, least of all in progressive scans -- FF fill bytes skipped), pack the symbol
-// tables each scan names, order the scans in dependency levels, run kp_scan level by level, then K2 as for any frame.
+// Host side of jd_decode_scans: copy every scan's raw bytes (16-byte aligned) into one upload, pack the symbol tables each
+// scan names, order the scans in dependency levels; on the device K0 unstuffs all scans in one launch the way
+// main.go:993-1021 does (FF00 -> FF, RSTn dropped -- the reference never acts on restart markers, least of all in
+// progressive scans -- FF fill bytes skipped: to K0 a scan is an image of one restart interval), kp_scan runs level by
+// level, then K2 as for any frame.
 namespace {
 
 struct DevBuf {                       // hipMalloc'ed scratch of one call
@@ -1104,23 +1106,6 @@ struct DevBuf {                       // hipMalloc'ed scratch of one call
     int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 256))); return JD_OK; }
 };
 
-// unstuff one scan (main.go:993-1021) at memchr speed: runs between FF bytes are copied whole
-int unstuff_scan(const uint8_t* e, size_t n, std::vector<uint8_t>& out) {
-    size_t i = 0;
-    while (i < n) {
-        const uint8_t* q = (const uint8_t*)memchr(e + i, 0xFF, n - i);
-        const size_t j = q ? (size_t)(q - e) : n;
-        out.insert(out.end(), e + i, e + j);
-        if (j + 1 >= n) break;                                 // (the parser ends the extent in front of the closing marker)
-        const uint8_t nx = e[j + 1];
-        if (nx == 0x00) { out.push_back(0xFF); i = j + 2; }
-        else if (nx >= 0xD0 && nx <= 0xD7) i = j + 2;          // RSTn: dropped
-        else if (nx == 0xFF) i = j + 1;                        // fill byte
-        else return JD_E_MARKER;
-    }
-    return JD_OK;
-}
-
 // n_images progressive files in one go: the scans of all of them are dealt to waves level by level, so a batch keeps the
 // chip busy where one file cannot (a scan is a serial chain).
 int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const* scans, const int* n_scans,
@@ -1128,12 +1113,13 @@ int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const
                       int16_t* coef_out, size_t coef_cap, int* status_out, int device) {
     if (n_images <= 0 || !frames || !scans || !n_scans || !files || !file_lens) return JD_E_ARG;
     if (coef_out && n_images != 1) return JD_E_ARG;
-    std::vector<uint8_t> stream;
+    std::vector<uint8_t> stream;                               // raw (stuffed) bytes of every scan
+    std::vector<uint32_t> raw_off;                             // per scan: where they lie in `stream`
+    size_t un_bytes = 0;                                       // device buffer of the unstuffed scans
     std::vector<uint32_t> lut(1, 0);                           // entry 0 stays unused
     std::vector<JdPScan> ps;
     std::vector<int> level;
     int n_levels = 0;
-    uint32_t max_lut_bytes = 0;                                // symbol tables of one scan (they sit in LDS beside the stream window)
     std::vector<jd_frame> fr(frames, frames + n_images);
     for (int im = 0; im < n_images; im++) {
         const jd_frame* frame = &frames[im];
@@ -1154,7 +1140,6 @@ int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const
             if (sc.ss == 0 && sc.se != 0) return JD_E_UNSUPPORTED; // T.81 G.1.1.1.1: a DC scan holds DC only (the reference would mix the cases up)
             if (sc.ss != 0 && sc.ncomp != 1) return JD_E_UNSUPPORTED;   // AC scans are never interleaved (the reference's skips counter assumes it)
             JdPScan d;
-            uint32_t scan_lut_bytes = 0;
             memset(&d, 0, sizeof d);
             d.img = (uint32_t)im; d.ss = sc.ss; d.se = sc.se; d.ah = sc.ah; d.al = sc.al; d.ncomp = sc.ncomp;
             // the reference walks the FRAME's components and decodes those the scan uses (main.go:771-775): ascending order
@@ -1170,19 +1155,19 @@ int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const
                     if (id > 3 || !sc.huff[need_dc ? 0 : 1][id].present) return JD_E_TABLE;
                     const jd_huff& h = sc.huff[need_dc ? 0 : 1][id];
                     d.lut_off[j] = (uint32_t)lut.size();
-                    if (jd_pack_lut_sym(h.bits, h.vals, h.nvals, lut)) return JD_E_TABLE;
+                    if (jd_pack_lut_lane(h.bits, h.vals, h.nvals, lut)) return JD_E_TABLE;
                     d.lut_len[j] = (uint32_t)lut.size() - d.lut_off[j];
-                    scan_lut_bytes += d.lut_len[j] * 4u;
                 }
             }
-            max_lut_bytes = std::max(max_lut_bytes, scan_lut_bytes);
+            // the scan's raw bytes, 16-byte aligned in the upload (K0 reads whole quads); its unstuffed bytes will lie at
+            // un_off + JD_STREAM_FRONT of the device's stream buffer, zeros behind them (kp_scan reads past the end as zeros)
             while (stream.size() % 16) stream.push_back(0);
-            if (stream.size() + sc.ecs_len + 64 >= (size_t)1 << 31) return JD_E_ARG;
-            d.stream_off = (uint32_t)stream.size();
-            rc = unstuff_scan(file + sc.ecs_off, sc.ecs_len, stream);
-            if (rc) return rc;
-            d.stream_len = (uint32_t)(stream.size() - d.stream_off);
-            stream.insert(stream.end(), 16, 0);
+            if (stream.size() + sc.ecs_len + 64 >= (size_t)1 << 31 || un_bytes + sc.ecs_len + 512 >= (size_t)1 << 31) return JD_E_ARG;
+            raw_off.push_back((uint32_t)stream.size());
+            stream.insert(stream.end(), file + sc.ecs_off, file + sc.ecs_off + sc.ecs_len);
+            d.stream_off = (uint32_t)un_bytes + JD_STREAM_FRONT;
+            d.stream_len = (uint32_t)sc.ecs_len;                  // raw length: the unstuffed one is K0's to tell (stream_len[] on the device)
+            un_bytes += align_up(JD_STREAM_FRONT + sc.ecs_len + JD_STREAM_TAIL + 64, 256);
             // dependency level: after every earlier scan of the file that touches one of its components in an overlapping band
             int lv = 0;
             for (int i = 0; i < k; i++) {
@@ -1200,14 +1185,13 @@ int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const
         for (int c = 0; c < fr[im].ncomp; c++) fr[im].comp[c].td = fr[im].comp[c].ta = 0;
         fr[im].restart_interval = 0;
     }
-    if (max_lut_bytes > 60u * 1024u) return JD_E_TABLE;
     // ---- device: a batch supplies geometry, quantisation tables, coefficient buffers and K2 ----
     jd_batch* b = nullptr;
     std::vector<size_t> caps(n_images, 16);
     int rc = jd_batch_create(device, n_images, fr.data(), caps.data(), JD_BATCH_KEEP_COEF | JD_BATCH_COEF16_, &b);
     if (rc) return rc;
     struct Guard { jd_batch* b; ~Guard() { batch_release(b); } } guard{ b };
-    DevBuf d_stream, d_lut, d_scans, d_list;
+    DevBuf d_stream, d_lut, d_scans, d_list, d_un, d_k0;
     std::vector<uint32_t> list;
     std::vector<int> level_start(n_levels + 1, 0);
     for (int l = 0; l < n_levels; l++) {
@@ -1217,7 +1201,36 @@ int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const
     if ((rc = d_stream.alloc(stream.size())) || (rc = d_lut.alloc(lut.size() * 4)) || (rc = d_scans.alloc(ps.size() * sizeof(JdPScan))) ||
         (rc = d_list.alloc(list.size() * 4))) return rc;
     hipStream_t s = b->stream;
+    // ---- K0 over the scans: one pseudo-image of one restart interval per scan -------------------------------------
+    const size_t nsc = ps.size();
+    std::vector<JdImg> pim(nsc);
+    std::vector<uint32_t> ppre(nsc + 1, 0);
+    for (size_t k = 0; k < nsc; k++) {
+        JdImg& q = pim[k];
+        memset(&q, 0, sizeof q);
+        q.ecs = (const uint8_t*)d_stream.p + raw_off[k]; q.ecs_len = ps[k].stream_len;
+        q.n_k0_chunks = (uint32_t)((q.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK);
+        q.n_intervals = 1; q.interval_base = (uint32_t)(2 * k);
+        q.stream_off = ps[k].stream_off - JD_STREAM_FRONT;
+        ppre[k + 1] = ppre[k] + q.n_k0_chunks;
+    }
+    // one block: JdImg[nsc] | prefix[nsc + 1] | status[nsc] | stream_len[nsc] | interval_start[2 nsc] | tickets | look-back words
+    const size_t o_img = 0, o_pre = align_up(nsc * sizeof(JdImg), 256), o_st = o_pre + align_up((nsc + 1) * 4, 256),
+                 o_len = o_st + align_up(nsc * 4, 256), o_iv = o_len + align_up(nsc * 4, 256), o_tk = o_iv + align_up(nsc * 8, 256),
+                 o_lb = o_tk + align_up((nsc + 64) * 4, 256), k0_bytes = o_lb + align_up(((size_t)ppre[nsc] + 32) * 8, 256);
+    if ((rc = d_un.alloc(un_bytes)) || (rc = d_k0.alloc(k0_bytes))) return rc;
+    uint8_t* const k0b = (uint8_t*)d_k0.p;
+    HIPCHK(hipMemsetAsync(d_un.p, 0, std::max<size_t>(un_bytes, 256), s));
+    HIPCHK(hipMemsetAsync(k0b + o_st, 0, o_iv - o_st, s));                     // scan status words and unstuffed lengths
+    HIPCHK(hipMemcpyAsync(k0b + o_img, pim.data(), nsc * sizeof(JdImg), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(k0b + o_pre, ppre.data(), (nsc + 1) * 4, hipMemcpyHostToDevice, s));
+    JdKernelArgs ka;
+    memset(&ka, 0, sizeof ka);
+    ka.imgs = (const JdImg*)(k0b + o_img); ka.n_images = (int)nsc; ka.stream = (uint8_t*)d_un.p;
+    ka.status = (uint32_t*)(k0b + o_st); ka.stream_len = (uint32_t*)(k0b + o_len); ka.interval_start = (uint32_t*)(k0b + o_iv);
+    ka.k0_ticket = (uint32_t*)(k0b + o_tk); ka.k0_state = (unsigned long long*)(k0b + o_lb);
     HIPCHK(hipMemcpyAsync(d_stream.p, stream.data(), stream.size(), hipMemcpyHostToDevice, s));
+    jdk_launch_k0(ka, (const uint32_t*)(k0b + o_pre), ppre[nsc], s);
     HIPCHK(hipMemcpyAsync(d_lut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_scans.p, ps.data(), ps.size() * sizeof(JdPScan), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, s));
@@ -1227,7 +1240,7 @@ int decode_scans_impl(int n_images, const jd_frame* frames, const jd_scan* const
     const JdKernelArgs a = kernel_args(b);
     for (int l = 0; l < n_levels; l++)
         jdk_launch_pscan(a, (const JdPScan*)d_scans.p, (const uint32_t*)d_list.p + level_start[l], level_start[l + 1] - level_start[l],
-                         (const uint8_t*)d_stream.p, (const uint32_t*)d_lut.p, max_lut_bytes, s);
+                         (const uint8_t*)d_un.p, (const uint32_t*)d_lut.p, ka.stream_len, ka.status, s);
     HIPCHK(hipGetLastError());
     rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
     b->ran = true; b->last_stream = s;

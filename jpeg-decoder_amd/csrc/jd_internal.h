@@ -160,15 +160,17 @@ static_assert(sizeof(JdSubCk) == 32 * (JD_CK_N + 1), "JdSubCk");
 // exclusive prefix of a sub-sequence inside its sync workgroup (block starts, DC-difference sums)
 struct JdSubPfx { uint32_t blk_off; int32_t dcp[3]; };
 
+// dwords of one progressive-scan symbol table (jd_pack_lut_lane: 7 rows of 64, one row per vector register)
+#define JD_PLUT_DWORDS 448
 // one scan of a progressive file (kp_scan: one wave per scan)
 struct JdPScan {
     uint32_t img;                // image whose coefficients the scan refines
-    uint32_t stream_off, stream_len;   // its unstuffed bytes in the scan-stream buffer (offset is 16-byte aligned)
+    uint32_t stream_off, stream_len;   // where K0 puts its unstuffed bytes in the scan-stream buffer (16-byte aligned); its RAW length
     uint32_t ss, se, ah, al;     // spectral selection and successive approximation (main.go:980-987)
     uint32_t ncomp;              // components in the scan ...
     uint32_t comp[3];            // ... their frame indices, ascending (the reference walks the frame's components)
     uint32_t lut_off[3], lut_len[3];   // ... and the symbol table each decodes through (DC tables in a DC scan, the AC table
-                                 // in an AC scan; none in a DC refinement): entry offset / entries in the table buffer
+                                 // in an AC scan; none in a DC refinement): dword offset in the table buffer / JD_PLUT_DWORDS
 };
 
 struct JdKernelArgs {

@@ -1272,6 +1272,7 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1_sync(JdKernelArgs a, int fix
         const uint64_t bm = __builtin_amdgcn_ballot_w64(changed);
         if ((threadIdx.x & 63u) == 0u) tmp[threadIdx.x >> 6] = (uint32_t)__popcll(bm);
         __syncthreads();
+        static_assert(JD_SYNC_WG == 256, "k1_sync sums the changed-lane counts of exactly four waves (n0 .. n3) and places gathered lanes by them");
         const uint32_t n0 = tmp[0], n1 = tmp[1], n2 = tmp[2], n3 = tmp[3];
         const uint32_t n = n0 + n1 + n2 + n3;
         if (n == 0) break;
@@ -1428,39 +1429,93 @@ __global__ __launch_bounds__(1024) void k1_dc_scan(JdKernelArgs a) {
 // host orders them in levels).  Coefficients accumulate in the same int16 buffer, same layout, as the baseline writer's;
 // K2 then runs unchanged.
 //
-// Inside a scan the symbols are a serial chain: lane 0 walks it, out of LDS only -- the scan's symbol tables and a 2 KiB
-// window of its bytes are staged there by all 64 lanes.  What does not depend on the chain runs wave-wide:
-//   * DC refinement (main.go:312-320) is one bit per block at a known position: 64 blocks per step, one per lane;
-//   * AC refinement (main.go:321-427) reads a correction bit for every coefficient that is already non-zero: the 64 lanes
-//     hold the block (one coefficient each, the next block's already loading), a wave ballot hands lane 0 the non-zero
-//     mask, lane 0 turns symbols and correction bits into three 64-bit masks (corrected / new / new-and-negative), and the
-//     lanes apply them to their own coefficient and store it if it changed.
+// Inside a scan the symbols are a serial chain, and a serial chain is SCALAR work: the walk runs on the wave's scalar unit
+// (bit buffer, positions, EOB-run counter, 64-bit coefficient masks all live in scalar registers; s_lshl_b64, s_ff1_i32_b64,
+// s_bcnt1_i32_b64 are single instructions there), and the data it looks things up in sits in VECTOR registers, read with
+// v_readlane (a few cycles, no memory round trip):
+//   * the scan's symbol tables (jd_pack_lut_lane: 7 registers per table -- a 256-entry primary table indexed by the next 8
+//     bits, MAXCODE / VALPTR per code length for the rare longer codes, the symbols);
+//   * a 512-byte window of the stream in two registers (lane l = dword l; the second is the prefetch of the next 256
+//     bytes, issued 2048 bits before it is needed).
+// (Round 2 walked the chain with lane 0 out of LDS: about 900 cycles per symbol, most of it LDS round trips of a lone wave.)
+// What does not depend on the chain runs wave-wide:
+//   * the 64 lanes hold the current block, one coefficient each: a first-visit AC coefficient is placed with v_writelane and
+//     the lanes that received one store it; DC values of 64 blocks are collected the same way and stored together;
+//   * DC refinement (main.go:312-320) is one bit per block at a known position: lane l handles block 64 i + l;
+//   * AC refinement (main.go:321-427) reads a correction bit for every coefficient that is already non-zero: a wave ballot
+//     gives the scalar walk the block's non-zero mask; for every symbol it works out WHICH coefficients take correction
+//     bits (mask arithmetic: the (run+1)-th zero at or after the current index) and reads that many bits at once; each lane
+//     finds its own bit by its rank in the mask (v_mbcnt) and corrects its coefficient.
 // ------------------------------------------------------------------------------------------------
-#define JD_P_RING_DW 512u                                       // stream window in LDS: two halves of 1 KiB
-struct PBits {                 // MSB-first reader (BitReader, main.go:1252-1295) over the LDS window; lane 0 only
-    uint32_t ring;             // byte offset of the window in dyn_lds
-    uint32_t next;             // next stream dword to take (absolute index; the window holds the JD_P_RING_DW around it)
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// lane `l` of v <- val (both wave-uniform): a compare against the lane number and a select -- what v_writelane_b32 does,
+// spelt in operations the compiler can schedule (this hipcc has no builtin for the instruction)
+__device__ __forceinline__ uint32_t wrlane(uint32_t val, uint32_t l, uint32_t v) { return threadIdx.x == l ? val : v; }
+
+struct PTab { uint32_t p0, p1, p2, p3, mx, off, vals; };       // one symbol table: what THIS lane holds of its seven rows
+__device__ __forceinline__ PTab ptab_load(const uint32_t* __restrict__ g, uint32_t lane, bool have) {
+    PTab t;
+    t.p0 = t.p1 = t.p2 = t.p3 = t.off = t.vals = 0; t.mx = 0xFFFFFFFFu;
+    if (have) { t.p0 = g[lane]; t.p1 = g[64 + lane]; t.p2 = g[128 + lane]; t.p3 = g[192 + lane]; t.mx = g[256 + lane]; t.off = g[320 + lane]; t.vals = g[384 + lane]; }
+    return t;
+}
+
+struct PBits {                 // MSB-first reader (BitReader, main.go:1252-1295); every member is wave-uniform
+    // the scan's unstuffed bytes, read through the CONSTANT address space: s_load_dword, straight into scalar registers
+    // (a dword ahead: the load issued at one refill is waited for at the next, some five symbols later)
+    const __attribute__((address_space(4))) uint32_t* stream;
+    uint32_t ndw;              // dwords of data; dword ndw and the ones after it are zero padding (the host leaves 16 bytes)
+    uint32_t next;             // dwords taken into `acc` so far
+    uint32_t ahead;            // dword `next`, already loaded (memory byte order)
     uint64_t acc;              // unread bits, left aligned
     int n;                     // how many
-    uint32_t used;             // bits consumed
-    __device__ __forceinline__ void fill() {
-        if (n <= 32) { const uint32_t d = lds_u32(ring + ((next & (JD_P_RING_DW - 1u)) << 2)); next++; acc |= (uint64_t)d << (32 - n); n += 32; }
+    __device__ __forceinline__ uint32_t load(uint32_t i) const { return stream[i < ndw ? i : ndw]; }   // past the end: zeros (readBit -1 is reported at the end)
+    __device__ __forceinline__ void init(const uint32_t* s, uint32_t nd) {
+        stream = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)s; ndw = nd; next = 0; acc = 0; n = 0;
+        ahead = load(0);
     }
-    __device__ __forceinline__ uint32_t get(uint32_t k) {    // readBits (k <= 16; 0 bits = 0)
+    __device__ __forceinline__ void fill() {                  // afterwards n >= 33
+        if (n <= 32) {
+            const uint32_t d = be32(ahead);
+            next++;
+            ahead = load(next);
+            acc |= (uint64_t)d << (32 - n); n += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t k) {     // readBits, k <= 32 (0 bits = 0)
         fill();
-        const uint32_t v = k ? (uint32_t)(acc >> (64 - k)) : 0u;
-        acc <<= k; n -= (int)k; used += k;
+        const uint32_t v = k ? (uint32_t)(acc >> (64u - k)) : 0u;
+        acc <<= k; n -= (int)k;
         return v;
     }
+    // ... without the refill test: up to 16 bits right behind a symbol (pscan_symbol refilled to >= 33 and took <= 16)
+    __device__ __forceinline__ uint32_t take(uint32_t k) {
+        const uint32_t v = k ? (uint32_t)(acc >> (64u - k)) : 0u;
+        acc <<= k; n -= (int)k;
+        return v;
+    }
+    __device__ __forceinline__ uint32_t used() const { return next * 32u - (uint32_t)n; }   // bits consumed
 };
-// scanSymbol (main.go:1297-1316) by table lookup (table in LDS); returns 0x100 for a code the table does not have
-__device__ __forceinline__ uint32_t pscan_symbol(PBits& br, uint32_t lut) {
+// scanSymbol (main.go:1297-1316) by table lookup; returns 0x100 for a code the table does not have
+__device__ __forceinline__ uint32_t pscan_symbol(PBits& br, const PTab& t) {
     br.fill();
-    uint32_t e = lds_u32(lut + ((uint32_t)(br.acc >> (64 - JD_LUT_BITS)) << 2));
-    if (e & 0x80000000u) e = lds_u32(lut + (((e & 0x7FFFFFFFu) + ((uint32_t)(br.acc >> (64 - JD_LUT_BITS - 6)) & 63u)) << 2));
-    if (e == 0) return 0x100u;
+    const uint32_t idx = (uint32_t)(br.acc >> 56), l = idx & 63u, h = idx >> 6;
+    const uint32_t a = rdlane(t.p0, l), b = rdlane(t.p1, l), c = rdlane(t.p2, l), d = rdlane(t.p3, l);
+    uint32_t e = h == 0u ? a : h == 1u ? b : h == 2u ? c : d;
+    if (__builtin_expect(e == 0u, 0)) {                       // longer than 8 bits: T.81 F.2.2.3, lengths 9 .. 16
+#pragma unroll 1
+        for (uint32_t L = 9; L <= 16u; L++) {
+            const uint32_t code = (uint32_t)(br.acc >> (64u - L));
+            if ((int)code <= (int)rdlane(t.mx, L - 1u)) {
+                const uint32_t i = (code + rdlane(t.off, L - 1u)) & 255u;
+                e = (L << 8) | ((rdlane(t.vals, i >> 2) >> ((i & 3u) * 8u)) & 0xFFu);
+                break;
+            }
+        }
+        if (e == 0u) return 0x100u;
+    }
     const uint32_t len = e >> 8;
-    br.acc <<= len; br.n -= (int)len; br.used += len;
+    br.acc <<= len; br.n -= (int)len;
     return e & 0xFFu;
 }
 __device__ __forceinline__ int pextend(uint32_t v, uint32_t len) {   // main.go:248-250 / 292-294
@@ -1468,12 +1523,18 @@ __device__ __forceinline__ int pextend(uint32_t v, uint32_t len) {   // main.go:
 }
 
 __global__ __launch_bounds__(64) void kp_scan(JdKernelArgs a, const JdPScan* __restrict__ scans, const uint32_t* __restrict__ list,
-                                               const uint8_t* __restrict__ pstream, const uint32_t* __restrict__ plut) {
-    const JdPScan sc = scans[list[blockIdx.x]];
+                                               const uint8_t* __restrict__ pstream, const uint32_t* __restrict__ plut,
+                                               const uint32_t* __restrict__ plen, const uint32_t* __restrict__ pstatus) {
+    const uint32_t scan_id = list[blockIdx.x];
+    const JdPScan sc = scans[scan_id];
     const JdImg& im = a.imgs[sc.img];
     const uint32_t lane = threadIdx.x;
+    // K0 unstuffed the scan (to it an image of one restart interval): its verdict on markers other than RSTn counts,
+    // its restart bookkeeping does not (the reference drops RSTn in a progressive scan, main.go:999-1000)
+    if (pstatus[scan_id] & JD_ST_MARKER) { if (lane == 0) atomicOr(&a.status[sc.img], (uint32_t)JD_ST_MARKER); return; }
     const uint32_t* __restrict__ stream = reinterpret_cast<const uint32_t*>(pstream + sc.stream_off);
-    const uint32_t ndw = (sc.stream_len + 3u) >> 2;
+    const uint32_t slen = plen[scan_id];                        // unstuffed bytes
+    const uint32_t ndw = (slen + 3u) >> 2;
     int16_t* const cf = a.coef + im.coef_off;
     const uint32_t hs = im.hs, vs = im.vs, nl = hs * vs;
     const uint32_t hsh = hs - 1u, vsh = vs - 1u;                // sampling factors are 1 or 2: divide and modulo by shift and mask
@@ -1483,190 +1544,167 @@ __global__ __launch_bounds__(64) void kp_scan(JdKernelArgs a, const JdPScan* __r
     const bool lum_only = sc.ncomp == 1 && sc.comp[0] == 0;
     const uint32_t xstep = lum_only ? 1u : hs, ystep = lum_only ? 1u : vs;
     const uint32_t ss = sc.ss, se = sc.se, al = sc.al;
+    const uint32_t mcux = im.mcux, bpm = im.bpm;
+    const uint32_t cpA = sc.comp[0], cpB = sc.comp[1], cpC = sc.comp[2];
     uint32_t err = 0;
+    // element offset (in int16) of block (bx, by) of component cp
+    auto block_off = [&](uint32_t cp, uint32_t bx, uint32_t by) -> uint32_t {
+        const uint32_t mcu = (by >> vsh) * mcux + (bx >> hsh);
+        const uint32_t b = cp ? nl + cp - 1u : (by & vsh) * hs + (bx & hsh);
+        return (mcu * bpm + b) * 64u;
+    };
+    // blocks per step of the walk (one (x, y) of the loops at main.go:769-770) and its steps per row
+    const uint32_t nA = (lum_only || cpA) ? 1u : nl, nB = sc.ncomp > 1 ? ((lum_only || cpB) ? 1u : nl) : 0u,
+                   nC = sc.ncomp > 2 ? ((lum_only || cpC) ? 1u : nl) : 0u;
+    const uint32_t per_step = nA + nB + nC;
+    const uint32_t steps_x = (bw + xstep - 1u) / xstep, steps_y = (bh + ystep - 1u) / ystep;
+    // block number n of the scan's walk -> its element offset (vector code: every lane its own n)
+    auto nth_block = [&](uint32_t n) -> uint32_t {
+        const uint32_t step = n / per_step;
+        uint32_t j = n - step * per_step;
+        const uint32_t sy = step / steps_x, sx = step - sy * steps_x;
+        uint32_t cp = cpA, cnt = nA;
+        if (j >= nA) { j -= nA; cp = cpB; cnt = nB; if (j >= nB) { j -= nB; cp = cpC; cnt = nC; } }
+        const uint32_t u = cnt > 1u ? j / hs : 0u, v = cnt > 1u ? j - u * hs : 0u;       // (u outer, v inner: main.go:785-786)
+        return block_off(cp, sx * xstep + v, sy * ystep + u);
+    };
 
-    // ---- DC refinement: block n of the scan takes bit n; 64 blocks per step ----------------------------------
+    // ---- DC refinement: block n of the scan takes bit n; lane l handles blocks 64 i + l ---------------------------
     if (ss == 0 && sc.ah != 0) {
-        uint32_t n = 0;
-        for (uint32_t y = 0; y < bh; y += ystep)
-            for (uint32_t x = 0; x < bw; x += xstep)
-                for (uint32_t k = 0; k < sc.ncomp; k++) {
-                    const uint32_t cp = k == 0 ? sc.comp[0] : (k == 1 ? sc.comp[1] : sc.comp[2]);   // (no indexed access: it would live in scratch memory)
-                    const uint32_t umax = (lum_only || cp) ? 1u : vs, vmax = (lum_only || cp) ? 1u : hs;
-                    for (uint32_t u = 0; u < umax; u++)
-                        for (uint32_t v = 0; v < vmax; v++, n++) {
-                            if ((n & 63u) != lane) continue;
-                            const uint32_t bx = x + v, by = y + u;
-                            const uint32_t mcu = (by >> vsh) * im.mcux + (bx >> hsh);
-                            const uint32_t b = cp ? nl + cp - 1u : (by & vsh) * hs + (bx & hsh);
-                            const uint32_t d = (n >> 5) < ndw ? be32(stream[n >> 5]) : 0u;
-                            int16_t* p = cf + ((uint64_t)mcu * im.bpm + b) * 64u;
-                            *p = (int16_t)(*p | (int)(((d >> (31u - (n & 31u))) & 1u) << al));
-                        }
-                }
-        if (lane == 0 && n > sc.stream_len * 8u) atomicOr(&a.status[sc.img], (uint32_t)JD_ST_TRUNC);   // readBit -1 (main.go:1273)
+        const uint32_t total = steps_x * steps_y * per_step;
+        for (uint32_t n = lane; n < total; n += 64u) {
+            const uint32_t d = (n >> 5) < ndw ? be32(stream[n >> 5]) : 0u;
+            int16_t* p = cf + nth_block(n);
+            *p = (int16_t)(*p | (int)(((d >> (31u - (n & 31u))) & 1u) << al));
+        }
+        if (lane == 0 && total > slen * 8u) atomicOr(&a.status[sc.img], (uint32_t)JD_ST_TRUNC);   // readBit -1 (main.go:1273)
         return;
     }
 
-    // ---- everything else: a serial chain of symbols, walked by lane 0 out of LDS -----------------------------------
-    // (components, tables and predictors are kept in named scalars: an indexed array would live in scratch memory, and the
-    // symbol loop would pay a memory round trip per access)
-    const uint32_t ring = 0, lutA = JD_P_RING_DW * 4u;
-    const uint32_t lutB = lutA + sc.lut_len[0] * 4u, lutC = lutB + (sc.ncomp > 1 ? sc.lut_len[1] * 4u : 0u);
-    auto stage_table = [&](uint32_t at, uint32_t off, uint32_t len) {
-        const uint32_t* src = plut + off;
-        for (uint32_t i = lane; i < len; i += 64u) *reinterpret_cast<uint32_t*>(dyn_lds + at + i * 4u) = src[i];
-    };
-    stage_table(lutA, sc.lut_off[0], sc.lut_len[0]);
-    if (sc.ncomp > 1) stage_table(lutB, sc.lut_off[1], sc.lut_len[1]);
-    if (sc.ncomp > 2) stage_table(lutC, sc.lut_off[2], sc.lut_len[2]);
-    const uint32_t cpA = sc.comp[0], cpB = sc.comp[1], cpC = sc.comp[2];
-    uint32_t filled = 0;                                       // stream dwords staged so far (wave-uniform)
-    auto top_up = [&](uint32_t next) {                         // keep >= 1 KiB staged ahead of the reader
-        while (filled < next + 256u) {
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t i = filled + j * 64u + lane;
-                *reinterpret_cast<uint32_t*>(dyn_lds + ring + ((i & (JD_P_RING_DW - 1u)) << 2)) = i < ndw ? be32(stream[i]) : 0u;
-            }
-            filled += 256u;
-        }
-    };
-    top_up(0); top_up(256u);
-    wave_lds_order();
-    PBits br; br.ring = ring; br.next = 0; br.acc = 0; br.n = 0; br.used = 0;
-    int predA = 0, predB = 0, predC = 0;                        // prevDC of the scan's components (main.go:750)
-    uint32_t skips = 0;
-    const bool refine = ss != 0 && sc.ah != 0;
+    // ---- everything else: a serial chain of symbols, walked on the scalar unit.  An error ends the scan (`goto done`:
+    // loops that also test an error flag cost the walk a dozen scalar instructions per symbol). -----------------------
+    const PTab tA = ptab_load(plut + sc.lut_off[0], lane, true);
+    PBits br; br.init(stream, ndw);
     const int positive = 1 << al, negative = -(1 << al);
-    const uint32_t mcux = im.mcux, bpm = im.bpm;
-    auto block_ptr = [&](uint32_t cp, uint32_t bx, uint32_t by) {
-        const uint32_t mcu = (by >> vsh) * mcux + (bx >> hsh);
-        const uint32_t b = cp ? nl + cp - 1u : (by & vsh) * hs + (bx & hsh);
-        return cf + ((uint64_t)mcu * bpm + b) * 64u;
-    };
-    // AC scans hold one component (checked by the host): its blocks in walk order are (x, y) stepping as above
-    int cur = 0;                                               // refinement: this lane's coefficient of the current block
-    if (refine) cur = block_ptr(cpA, 0, 0)[lane];
-    for (uint32_t y = 0; y < bh && !err; y += ystep)
-        for (uint32_t x = 0; x < bw && !err; x += xstep) {
-            top_up(__builtin_amdgcn_readfirstlane(br.next));
-            wave_lds_order();
-            if (!refine) {
-                if (lane == 0) {
-                    if (ss == 0) {                             // DC first visit, main.go:243-253: the MCU's blocks of each component
-                        auto dc_first = [&](uint32_t cp, uint32_t lutk, int& pred) {
-                            const uint32_t umax = (lum_only || cp) ? 1u : vs, vmax = (lum_only || cp) ? 1u : hs;
-                            for (uint32_t u = 0; u < umax && !err; u++)
-                                for (uint32_t v = 0; v < vmax && !err; v++) {
-                                    const uint32_t sym = pscan_symbol(br, lutk);
-                                    if (sym > 16u) { err |= JD_ST_HUFF; break; }
-                                    const int val = pextend(br.get(sym), sym) + pred;
-                                    pred = val;
-                                    const int out = val << al;
-                                    if (out != (int)(short)out) err |= JD_ST_COEF;
-                                    block_ptr(cp, x + v, y + u)[0] = (int16_t)out;
-                                }
-                        };
-                        dc_first(cpA, lutA, predA);
-                        if (sc.ncomp > 1 && !err) dc_first(cpB, lutB, predB);
-                        if (sc.ncomp > 2 && !err) dc_first(cpC, lutC, predC);
-                    } else if (skips > 0) {                    // AC first visit, main.go:254-311: inside an end-of-band run
-                        skips -= 1;
-                    } else {
-                        int16_t* blk = block_ptr(cpA, x, y);
-                        uint32_t index = ss;
-                        while (index <= se) {
-                            const uint32_t sym = pscan_symbol(br, lutA);
-                            if (sym > 0xFFu) { err |= JD_ST_HUFF; break; }
-                            if (sym == 0xF0u) {                // sixteen zeros (already there: first visit)
-                                if (index + 16u > 64u) { err |= JD_ST_COEF; break; }
-                                index += 16u;
-                                continue;
-                            }
-                            const uint32_t zeros = sym >> 4, len = sym & 15u;
-                            if (len == 0) { skips = ((1u << zeros) - 1u) + br.get(zeros); break; }   // EOBn
-                            index += zeros;
-                            if (index > 63u) { err |= JD_ST_COEF; break; }
-                            const int out = pextend(br.get(len), len) << al;
-                            if (out != (int)(short)out) err |= JD_ST_COEF;
-                            blk[index] = (int16_t)out;
-                            index++;
-                        }
+
+    if (ss == 0) {
+        // ---- DC first visit, main.go:243-253: the blocks of each component of every step, in walk order.  Values and
+        // block offsets of 64 blocks are collected in two vector registers and stored together.
+        const PTab tB = ptab_load(plut + sc.lut_off[1], lane, sc.ncomp > 1);
+        const PTab tC = ptab_load(plut + sc.lut_off[2], lane, sc.ncomp > 2);
+        int predA = 0, predB = 0, predC = 0;                   // prevDC of the scan's components (main.go:750)
+        uint32_t vval = 0, voff = 0, slot = 0;
+#define JD_P_DC_FIRST(cp, cnt, tab, pred)                                                                   \
+        for (uint32_t j = 0; j < (cnt); j++) {                                                              \
+            const uint32_t u = (cnt) > 1u ? j >> hsh : 0u, v = (cnt) > 1u ? j & hsh : 0u;                   \
+            const uint32_t sym = pscan_symbol(br, tab);                                                     \
+            if (sym > 16u) { err |= JD_ST_HUFF; goto dc_done; }                                             \
+            const int val = pextend(br.take(sym), sym) + pred;                                               \
+            pred = val;                                                                                     \
+            const int out = val << al;                                                                      \
+            if (out != (int)(short)out) { err |= JD_ST_COEF; goto dc_done; }                                \
+            vval = wrlane((uint32_t)out, slot, vval);                                                       \
+            voff = wrlane(block_off(cp, x + v, y + u), slot, voff);                                         \
+            if (++slot == 64u) { cf[voff] = (int16_t)vval; slot = 0; }                                      \
+        }
+        for (uint32_t y = 0; y < bh; y += ystep)
+            for (uint32_t x = 0; x < bw; x += xstep) {
+                JD_P_DC_FIRST(cpA, nA, tA, predA)
+                JD_P_DC_FIRST(cpB, nB, tB, predB)
+                JD_P_DC_FIRST(cpC, nC, tC, predC)
+            }
+#undef JD_P_DC_FIRST
+    dc_done:
+        if (lane < slot) cf[voff] = (int16_t)vval;
+    } else if (sc.ah == 0) {
+        // ---- AC first visit, main.go:254-311 (one component: checked by the host).  The band is zero before this scan: the
+        // lanes start from zero, a coded coefficient is dropped into its lane, and only those lanes store (another scan of
+        // the same level may be writing the block's other band at this very moment).
+        uint32_t skips = 0;
+        for (uint32_t y = 0; y < bh; y += ystep)
+            for (uint32_t x = 0; x < bw; x += xstep) {
+                if (skips > 0) { skips -= 1; continue; }       // inside an end-of-band run
+                uint32_t v = 0;
+                uint64_t wrote = 0;
+                uint32_t index = ss;
+                while (index <= se) {
+                    const uint32_t sym = pscan_symbol(br, tA);
+                    if (sym > 0xFFu) { err |= JD_ST_HUFF; goto done; }
+                    if (sym == 0xF0u) {                        // sixteen zeros (already there: first visit)
+                        if (index + 16u > 64u) { err |= JD_ST_COEF; goto done; }
+                        index += 16u;
+                        continue;
                     }
+                    const uint32_t zeros = sym >> 4, len = sym & 15u;
+                    if (len == 0) { skips = ((1u << zeros) - 1u) + br.take(zeros); break; }   // EOBn
+                    index += zeros;
+                    if (index > 63u) { err |= JD_ST_COEF; goto done; }
+                    const int out = pextend(br.take(len), len) << al;
+                    if (out != (int)(short)out) { err |= JD_ST_COEF; goto done; }
+                    v = wrlane((uint32_t)out, index, v);
+                    wrote |= 1ull << index;
+                    index++;
                 }
-            } else {
-                // AC refinement, main.go:321-427.  Next block in walk order: its coefficients start loading now.
+                if (wrote && ((wrote >> lane) & 1ull)) cf[block_off(cpA, x, y) + lane] = (int16_t)v;
+            }
+    } else {
+        // ---- AC refinement, main.go:321-427 ------------------------------------------------------------------------------
+        uint32_t skips = 0;
+        int cur = cf[block_off(cpA, 0, 0) + lane];             // this lane's coefficient of the current block
+        for (uint32_t y = 0; y < bh; y += ystep)
+            for (uint32_t x = 0; x < bw; x += xstep) {
+                // next block in walk order: its coefficients start loading now
                 uint32_t nx = x + xstep, ny = y;
                 if (nx >= bw) { nx = 0; ny = y + ystep; }
                 int nxt = 0;
-                if (ny < bh) nxt = block_ptr(cpA, nx, ny)[lane];
+                if (ny < bh) nxt = cf[block_off(cpA, nx, ny) + lane];
                 const uint64_t nz = __builtin_amdgcn_ballot_w64(cur != 0);
-                uint64_t corr = 0, born = 0, bneg = 0;         // lane 0's verdict on the block
-                if (lane == 0) {
-                    // The Go loop looks at one coefficient at a time (main.go:369-394); on the non-zero mask the same walk
-                    // is arithmetic: the symbol's target is the (zeroes + 1)-th zero at or after `index`, and every non-zero
-                    // coefficient passed on the way takes one correction bit, in index order.
-                    auto take_bits = [&](uint64_t m) {          // a correction bit for each coefficient of m, ascending
-                        while (m) {
-                            uint32_t k = (uint32_t)__popcll(m); k = k > 16u ? 16u : k;
-                            const uint32_t v = br.get(k);      // first bit read = top bit of v = lowest index
-                            for (uint32_t j = 0; j < k; j++) {
-                                const uint64_t low = m & (0ull - m);
-                                if ((v >> (k - 1u - j)) & 1u) corr |= low;
-                                m ^= low;
-                            }
-                        }
-                    };
-                    uint32_t index = ss;
-                    if (skips == 0) {
-                        while (index <= se) {
-                            const uint32_t sym = pscan_symbol(br, lutA);
-                            if (sym > 0xFFu) { err |= JD_ST_HUFF; break; }
-                            const uint32_t zeroes = sym >> 4, len = sym & 15u;
-                            bool neg = false;
-                            if (len != 0) {
-                                if (len != 1) { err |= JD_ST_COEF; break; }
-                                neg = br.get(1) == 0;
-                            }
-                            if (len == 0 && sym != 0xF0u) { skips = (1u << zeroes) + br.get(zeroes); break; }
-                            const uint64_t from = ~0ull << index;
-                            uint64_t z = ~nz & from;           // zero coefficients at or after index
-                            for (uint32_t k = 0; k < zeroes && z; k++) z &= z - 1ull;
-                            if (!z) { err |= JD_ST_COEF; break; }                  // the run walks past coefficient 63
-                            const uint32_t p = (uint32_t)__builtin_ctzll(z);
-                            take_bits(nz & from & ((1ull << p) - 1ull));
-                            if (len != 0) { born |= 1ull << p; if (neg) bneg |= 1ull << p; }   // (ZRL: the sixteenth zero stays zero)
-                            index = p + 1u;
-                        }
-                    }
-                    if (skips > 0 && !err) {                   // inside an end-of-band run: the rest of the band is only corrected
-                        if (index <= se) take_bits(nz & (~0ull << index) & (se == 63u ? ~0ull : (1ull << (se + 1u)) - 1ull));
-                        skips -= 1;
-                    }
-                }
-                // (readfirstlane returns int: without the casts a set bit 31 would sign-extend into the upper half)
-                auto lane0 = [](uint64_t m) {
-                    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
-                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
-                };
-                const uint64_t c64 = lane0(corr), b64 = lane0(born), n64 = lane0(bneg);
                 int val = cur;
-                if ((c64 >> lane) & 1ull) val = cur >= 0 ? cur + positive : cur + negative;
-                if ((b64 >> lane) & 1ull) val = ((n64 >> lane) & 1ull) ? negative : positive;
-                if (val != cur) {
-                    if (val != (int)(short)val) err |= JD_ST_COEF;
-                    block_ptr(cpA, x, y)[lane] = (int16_t)val;
+                // a correction bit for each coefficient of m, ascending (the Go loop looks at one coefficient at a time,
+                // main.go:369-394): read them all at once; the lane of rank r in m owns the r-th bit read
+                auto take_bits = [&](uint64_t m) {
+                    const uint32_t k = (uint32_t)__popcll(m);
+                    if (k == 0) return;
+                    const uint32_t k1 = k > 32u ? 32u : k, k2 = k - k1;
+                    uint64_t bits = br.get(k1);
+                    if (k2) bits = (bits << k2) | br.get(k2);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (((m >> lane) & 1ull) && ((bits >> (k - 1u - rank)) & 1ull)) val = cur >= 0 ? cur + positive : cur + negative;
+                };
+                uint32_t index = ss;
+                if (skips == 0) {
+                    while (index <= se) {
+                        const uint32_t sym = pscan_symbol(br, tA);
+                        if (sym > 0xFFu) { err |= JD_ST_HUFF; goto done; }
+                        const uint32_t zeroes = sym >> 4, len = sym & 15u;
+                        bool neg = false;
+                        if (len != 0) {
+                            if (len != 1) { err |= JD_ST_COEF; goto done; }
+                            neg = br.take(1) == 0;
+                        }
+                        if (len == 0 && sym != 0xF0u) { skips = (1u << zeroes) + br.take(zeroes); break; }
+                        const uint64_t from = ~0ull << index;
+                        uint64_t z = ~nz & from;               // zero coefficients at or after index
+                        for (uint32_t k = 0; k < zeroes && z; k++) z &= z - 1ull;
+                        if (!z) { err |= JD_ST_COEF; goto done; }   // the run walks past coefficient 63
+                        const uint32_t p = (uint32_t)__builtin_ctzll(z);
+                        take_bits(nz & from & ((1ull << p) - 1ull));
+                        if (len != 0 && lane == p) val = neg ? negative : positive;   // (ZRL: the sixteenth zero stays zero)
+                        index = p + 1u;
+                    }
                 }
+                if (skips > 0) {                               // inside an end-of-band run: the rest of the band is only corrected
+                    if (index <= se) take_bits(nz & (~0ull << index) & (se == 63u ? ~0ull : (1ull << (se + 1u)) - 1ull));
+                    skips -= 1;
+                }
+                if (val != cur) cf[block_off(cpA, x, y) + lane] = (int16_t)val;
+                if (__builtin_amdgcn_ballot_w64(val != (int)(short)val)) { err |= JD_ST_COEF; goto done; }
                 cur = nxt;
             }
-            if (__builtin_amdgcn_ballot_w64(err != 0)) {        // an error anywhere in the wave ends the scan
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) err |= __shfl_xor(err, d, 64);
-            }
-        }
-    if (lane == 0 && br.used > sc.stream_len * 8u) err |= JD_ST_TRUNC;             // readBit -1 (main.go:1273)
-    if (err) atomicOr(&a.status[sc.img], err);
+    }
+done:
+    if (br.used() > slen * 8u) err |= JD_ST_TRUNC;     // readBit -1 (main.go:1273)
+    if (err && lane == 0) atomicOr(&a.status[sc.img], err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2155,9 +2193,9 @@ void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s) {
 }
 
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
-                      const uint32_t* d_plut, uint32_t max_lut_bytes, hipStream_t s) {
+                      const uint32_t* d_plut, const uint32_t* d_plen, const uint32_t* d_pstatus, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(kp_scan, dim3(n), dim3(64), JD_P_RING_DW * 4u + max_lut_bytes, s, a, d_scans, d_list, d_pstream, d_plut);
+    hipLaunchKernelGGL(kp_scan, dim3(n), dim3(64), 0, s, a, d_scans, d_list, d_pstream, d_plut, d_plen, d_pstatus);
 }
 
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s) {

@@ -163,37 +163,34 @@ int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool i
     return 0;
 }
 
-int jd_pack_lut_sym(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint32_t>& out) {
+// Symbol table for the progressive scans, laid out for a decoder that runs on the SCALAR unit and keeps the table in
+// vector registers (kp_scan): 7 rows of 64 dwords, dword l of a row = what lane l holds.
+//   rows 0-3  primary table indexed by the next 8 bits of the stream: code length << 8 | symbol; 0 = the code is longer
+//   row 4     lane L-1: the largest code of length L (T.81 F.2.2.3 MAXCODE), -1 if there is none
+//   row 5     lane L-1: index of the first symbol of length L minus its code (VALPTR - MINCODE)
+//   row 6     the symbols, four to a dword
+int jd_pack_lut_lane(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint32_t>& out) {
     int count = 0;
     for (int i = 0; i < 16; i++) count += bits[i];
     if (count != nvals || nvals > 256) return -1;
     const size_t base = out.size();
-    out.resize(base + JD_LUT_PRIMARY, 0);
+    out.resize(base + JD_PLUT_DWORDS, 0);
     unsigned code = 0;
     int k = 0;
     for (unsigned len = 1; len <= 16; len++) {
+        out[base + 256 + len - 1] = 0xFFFFFFFFu;
+        out[base + 320 + len - 1] = (uint32_t)(k - (int)code);
         for (int i = 0; i < bits[len - 1]; i++, k++) {
             if (code >= (1u << len)) return -2;
-            const uint32_t e = (uint32_t)vals[k] | (len << 8);
-            if (len <= JD_LUT_BITS) {
-                const unsigned first = code << (JD_LUT_BITS - len), n = 1u << (JD_LUT_BITS - len);
-                for (unsigned j = 0; j < n; j++) out[base + first + j] = e;
-            } else {
-                const unsigned prefix = code >> (len - JD_LUT_BITS);
-                uint32_t p = out[base + prefix];
-                if (!(p & 0x80000000u)) {
-                    if (p != 0) return -2;
-                    const size_t off = out.size() - base;
-                    out.resize(out.size() + JD_LUT_SECONDARY, 0);
-                    p = 0x80000000u | (uint32_t)off;
-                    out[base + prefix] = p;
-                }
-                const unsigned sub = (code << (JD_LUT_BITS + 6 - len)) & 63u, n = 1u << (JD_LUT_BITS + 6 - len);
-                for (unsigned j = 0; j < n; j++) out[base + (p & 0x7FFFFFFFu) + sub + j] = e;
+            if (len <= 8) {
+                const unsigned first = code << (8 - len), n = 1u << (8 - len);
+                for (unsigned j = 0; j < n; j++) out[base + first + j] = (uint32_t)vals[k] | (len << 8);
             }
+            out[base + 256 + len - 1] = code;
             code++;
         }
         code <<= 1;
     }
+    for (int i = 0; i < nvals; i++) out[base + 384 + (i >> 2)] |= (uint32_t)vals[i] << ((i & 3) * 8);
     return 0;
 }

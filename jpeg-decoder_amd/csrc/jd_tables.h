@@ -17,7 +17,6 @@ int jd_pack_lut_bits(const uint8_t bits[16], const uint8_t* vals, int nvals, boo
 // unit: advance of one coefficient in the [15:8] field -- 2 (bytes of int16 coefficients; EOB 254) or 1 (byte form; EOB 127)
 int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned prim_bits, unsigned unit,
                   std::vector<uint32_t>& out);
-// Symbol table for the progressive scans (32-bit entries, JD_LUT_BITS primary + 64-entry secondaries): the decoder needs
-// the raw symbol there (run/size, EOBn), not a baseline interpretation of it.  Entry: [7:0] symbol, [15:8] code length;
-// bit 31 set: [30:0] offset of the secondary table; 0: no code starts with these bits.
-int jd_pack_lut_sym(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint32_t>& out);
+// Symbol table for the progressive scans: the decoder needs the raw symbol there (run/size, EOBn), not a baseline
+// interpretation of it.  JD_PLUT_DWORDS dwords, laid out for kp_scan's scalar-unit decoder (jd_tables.cpp).
+int jd_pack_lut_lane(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint32_t>& out);
