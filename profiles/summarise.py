@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (written by profiles/collect.sh) into the committed summaries under profiles/:
    <tag>_<wl>_kernel_stats.csv, <tag>_<wl>_bench.json, <tag>_<wl>_bench_under_rocprof.json, <tag>_traffic.json
-   (also copied to r02_traffic.json, which bench.py reads) and <tag>_sq_counters.json.
+   (also copied to rNN_traffic.json, NN from the tag: bench.py reads the newest) and <tag>_sq_counters.json.
 
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950 FETCH_SIZE tallies 128-byte
 fabric reads at 64 bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section), so it is doubled; WRITE_SIZE is exact.  Counters
@@ -63,10 +63,11 @@ for wl in ("c3", "c4", "c5"):
         continue
     (f, nl), (w, _) = per_kernel(fe[0]), per_kernel(wr[0])
     bench = json.load(open(os.path.join(src, "pmc_fetch_%s.json" % wl)))
-    steps = bench["steps"] + bench["warmup"]
+    # passes the profiled process made: three while it chose `steps_internal`, then (warmup + steps) x steps_internal
+    steps = 3 + (bench["steps"] + bench["warmup"]) * bench.get("steps_internal", 1)
     per_step = {k: max(1, round(nl[k] / steps)) for k in nl}
     traffic["workloads"][wl] = {
-        "images_per_step": bench["config"]["images_per_gpu_per_step"],
+        "images_per_step": bench["config"]["items_per_gpu_per_pass"],
         "algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_launch"],
         "kernels": {k: {"FETCH_SIZE_KiB_per_launch": round(f[k]), "WRITE_SIZE_KiB_per_launch": round(w.get(k, 0)),
                         "launches_per_step": per_step[k],
@@ -88,7 +89,7 @@ for wl in ("c3", "c4", "c5"):
     if cs:
         sq["workloads"][wl] = cs
 json.dump(traffic, open(os.path.join(root, tag + "_traffic.json"), "w"), indent=1)
-json.dump(traffic, open(os.path.join(root, "r02_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(root, tag.split("_")[0] + "_traffic.json"), "w"), indent=1)
 json.dump(sq, open(os.path.join(root, tag + "_sq_counters.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 print(json.dumps(sq, indent=1))
