@@ -52,6 +52,20 @@ def test_resident_matches_batch_on_calls_in_a_row():
         assert np.array_equal(got[:, :w * 3].reshape(h, w, 3), oracle), "case %d vs oracle" % k
 
 
+def test_resident_reuses_its_plan_for_the_same_frame():
+    """Calls with one jd_frame share the plan of the first (no table packing, no table upload): different pictures of the
+    same frame, one whose segment outgrows the planned capacity (re-planned), a smaller one again, each equal to the batch path."""
+    jd.init([0])
+    made = [jd.SynthImage(640, 480, 2, 2, 3, quality=85, seed=s, detail=d).encode(0) for s, d in ((3, 1), (6, 1), (1, 2), (2, 2), (3, 1), (5, 6))]
+    frames = [jd.parse(m)[0] for m in made]
+    assert all(bytes(f) == bytes(frames[0]) for f in frames)              # one frame: same geometry, same tables
+    lens = [jd.parse(m)[2] for m in made]
+    assert lens[2] > 1.25 * lens[0] + 65536 - 1 or lens[2] > 131072           # the third picture's segment outgrows the first plan's capacity
+    for m in made:
+        fr, ecs, ln = _dev_inputs(m)
+        assert np.array_equal(_resident_rgb(fr, ecs, ln, 640 * 3), _batch_rgb(fr, ecs, ln, 640 * 3))
+
+
 def test_resident_allocates_no_device_memory():
     jd.init([0])
     im = jd.SynthImage(800, 600, 2, 2, 3, quality=85, seed=5, detail=2)
