@@ -496,7 +496,8 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                     else jd_pack_lut_multi(h.bits, h.vals, h.nvals, JD_SLUT_BITS, sset);
                     it = placed.emplace(cls * 4 + id, off).first;
                     wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
-                    if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_WIDE : JD_W32_DC_BITS, unit, wset)) { batch_release(b); return JD_E_TABLE; }
+                    if (bytes && cls ? jd_pack_lut32p(h.bits, h.vals, h.nvals, JD_W32_AC_BITS_WIDE, wset)
+                                     : jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_WIDE : JD_W32_DC_BITS, unit, wset)) { batch_release(b); return JD_E_TABLE; }
                     key.append((const char*)h.bits, 16); key.append((const char*)h.vals, h.nvals); key.push_back((char)(cls * 4 + id));
                 }
                 (cls ? im.ac_lut : im.dc_lut)[c] = it->second;
@@ -517,7 +518,8 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                     if (!wplaced.count(cls * 4 + id)) {
                         wplaced.emplace(cls * 4 + id, (uint32_t)wset.size());
                         const jd_huff& h = f.huff[cls][id];
-                        if (jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_NARROW : JD_W32_DC_BITS, unit, wset)) { batch_release(b); return JD_E_TABLE; }
+                        if (bytes && cls ? jd_pack_lut32p(h.bits, h.vals, h.nvals, JD_W32_AC_BITS_NARROW, wset)
+                                         : jd_pack_lut32(h.bits, h.vals, h.nvals, cls == 0, cls ? JD_W32_AC_BITS_NARROW : JD_W32_DC_BITS, unit, wset)) { batch_release(b); return JD_E_TABLE; }
                     }
                     (cls ? im.wac : im.wdc)[c] = wplaced[cls * 4 + id];
                 }

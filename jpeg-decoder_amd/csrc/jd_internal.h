@@ -40,6 +40,21 @@
 #define JD_W32_EOB_ADV 254u
 #define JD_W32_EOB_ADV8 127u        // byte form (write_segments8): the advance counts coefficients, not bytes
 
+// ---- pair tables of the byte-form writer (AC; jd_pack_lut32p) ---------------------------------------------------------
+// Same shape as the writer tables above (2^P primary entries + secondary tables), but an entry describes up to TWO
+// symbols, and a single symbol is a pair whose second half is empty (size 0, advance 0): one code path in the decoder.
+//   [4:0]   sh2: 32 - bits of both symbols (codes + magnitudes): the right shift that brings symbol 2's magnitude down,
+//           and what the window advances by
+//   [7:5]   size2: magnitude bits of symbol 2 (0 .. 7)
+//   [15:8]  adv1: coefficients symbol 1 advances by (run + 1; 16 for ZRL; JD_WP_EOB_ADV for EOB)
+//   [22:16] adv2: the same for symbol 2; 0 = there is none
+//   [27:23] sh1: 32 - bits of symbol 1 (= sh2 in a single)
+//   [31:28] size1: magnitude bits of symbol 1; >= 8 (bit 31) only in singles -- the decoder keeps such a value's high part
+//   bit 31 set and adv1 = 0: [27:16] offset (in entries, from the table start) of a secondary table; offset 0 = no such code
+// A block that ends with symbol 1 (coefficient 63 reached) ignores symbol 2 and advances by symbol 1 alone.
+#define JD_WP_EOB_ADV 127u
+#define JD_WP_SKIP (31u | (JD_WP_EOB_ADV << 8) | (31u << 23))   // stand-in for an invalid code: one bit, end of block
+
 // self-synchronising decode: bits per sub-sequence (one lane each)
 #ifndef JD_SUBSEQ_BITS
 #define JD_SUBSEQ_BITS 4096u

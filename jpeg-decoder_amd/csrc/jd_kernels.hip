@@ -462,6 +462,16 @@ __device__ __forceinline__ int w32_value(uint32_t win, uint32_t e) {
     return (int)raw - (int)(raw <= (e >> 17) ? m : 0u);            // e >> 17 = 2^(size-1) - 1
 }
 
+// pair tables (JD_WP_*, jd_internal.h): magnitude bits + EXTEND of one symbol.  `off` / `size`: only their low five bits
+// count (v_bfe_i32 reads no more), so the entry shifted right by the field's position is operand enough.  The signed field y
+// is raw - 2^size when the first magnitude bit is set (a positive value: v = raw) and raw otherwise (v = raw - (2^size - 1));
+// with m = 2^size - 1 and u = y >> 31 both cases are v = y - (m ^ u).
+__device__ __forceinline__ int wp_value(uint32_t win, uint32_t off, uint32_t size) {
+    const int y = __builtin_amdgcn_sbfe((int)win, off, size);
+    const uint32_t m = (1u << (size & 31u)) - 1u;
+    return y - (int)(m ^ (uint32_t)(y >> 31));
+}
+
 // raw_dc (wave-uniform): store each block's DC DIFFERENCE instead of the predicted value -- k1_dc_scan turns the
 // differences into predictions afterwards (images whose block-in-MCU phase cannot self-synchronise).
 template <bool NT>
@@ -855,16 +865,9 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         for (int i = 0; i < 4; i++) ((g_u4*)hib)[i] = z;
         hib[0] = (uint8_t)((uint32_t)pred >> 8);
         uint32_t junk = 0, ac63_hi = 0;
-        uint32_t e = w32_lookup(dcb, window(pos), JD_W32_DC_BITS, junk);
-        pos += 32u - (e & 31u);
-        uint32_t k = 0;
-        while (k < 63u) {
-            const uint32_t win = window(pos);
-            e = w32_lookup(acb, win, ac_bits, junk);
-            const int v = w32_value(win, e);
-            pos += 32u - (e & 31u);
-            k += (e >> 8) & 255u;
-            if (k > 63u) break;
+        const uint32_t ed = w32_lookup(dcb, window(pos), JD_W32_DC_BITS, junk);
+        pos += 32u - (ed & 31u);
+        auto high_part = [&](uint32_t k, int v) {
             if (k == 63u) {
                 hib[63] = (uint8_t)v; ac63_hi = ((uint32_t)v >> 8) & 15u;
                 if (v != ((v << 20) >> 20)) err |= JD_ST_COEF;
@@ -872,6 +875,25 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
                 const int hc = (v - (int)(int8_t)v) >> 8;
                 if (hc != 0) hib[k] = (uint8_t)hc;
             }
+        };
+        uint32_t k = 0;
+        while (k < 63u) {
+            const uint32_t win = window(pos);
+            uint32_t e = la_u32(acb + ((win >> (30u - ac_bits)) & (((1u << ac_bits) - 1u) << 2)));
+            if ((int)e < 0 && ((e >> 8) & 255u) == 0u) {
+                const uint32_t so = (e >> 16) & 0xFFFu;
+                e = so ? la_u32(acb + (so << 2) + ((win >> 14) & ((0xFFFFu >> ac_bits) << 2))) : JD_W32_NONE;
+                if (((e >> 8) & 255u) == 0u) e = JD_WP_SKIP;
+            }
+            k += (e >> 8) & 255u;
+            if (k > 63u) break;
+            high_part(k, wp_value(win, e >> 23, e >> 28));
+            const uint32_t adv2 = (e >> 16) & 127u;
+            if (k == 63u || adv2 == 0u) { pos += 32u - ((e >> 23) & 31u); continue; }   // symbol 1 alone
+            pos += 32u - (e & 31u);
+            k += adv2;
+            if (k > 63u) break;
+            high_part(k, wp_value(win, e, (e >> 5) & 7u));
         }
         return ac63_hi;
     };
@@ -908,38 +930,49 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             o = 0;
         }
         int v = 0;
+        // One lookup resolves up to two symbols (pair tables, JD_WP_*): the steps of the dependent chain -- window, table
+        // look-up, length, window -- are what the loop waits for, and at quality 85 a lookup now covers 1.4 symbols.
         while (o < 63u) {                                                 // divergent loop: finished lanes drop out
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up_now();
             const uint32_t cand = ring_at(rpb);
             const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
             e = la_u32(acb + ((win >> (30u - ac_bits)) & (((1u << ac_bits) - 1u) << 2)));
-            // ONE test for everything rare: a secondary-table pointer and "no such code" have bit 31 set (jd_tables.cpp),
-            // an entry of magnitude category >= 8 has bit 23 of its mask field set
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(e >= (1u << 23)) != 0, 0) && e >= (1u << 23)) {   // (one wave-wide branch in the common case)
-                if ((int)e < 0) {
-                    const uint32_t so = e & 0x7FFFFFFFu;
+            // ONE test for everything rare: bit 31 marks a secondary-table pointer, "no such code" and a first symbol of
+            // magnitude category >= 8 (always a single)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64((int)e < 0) != 0, 0) && (int)e < 0) {   // (one wave-wide branch in the common case)
+                if (((e >> 8) & 255u) == 0u) {
+                    const uint32_t so = (e >> 16) & 0xFFFu;
                     e = so ? la_u32(acb + (so << 2) + ((win >> 14) & ((0xFFFFu >> ac_bits) << 2))) : JD_W32_NONE;
-                    if ((int)e < 0) { bad = 1; e = JD_W32_SKIP; }
+                    if (((e >> 8) & 255u) == 0u) { bad = 1; e = JD_WP_SKIP; }
                 }
-                if (e >= (1u << 23)) {                                    // keep the high part (the low byte is stored below)
-                    const int wv = w32_value(win, e);
+                if ((int)e < 0) {                                         // keep the high part (the low byte is stored below)
+                    const int wv = wp_value(win, e >> 23, e >> 28);
                     const uint32_t wo = o + ((e >> 8) & 255u);
                     wl1 = (wl1 << 16) | (wl0 >> 16);
                     wl0 = (wl0 << 16) | ((wo & 255u) << 8) | (((uint32_t)(wv - (int)(int8_t)wv) >> 8) & 0xFFu);
                     wcnt++;
                 }
             }
-            v = w32_value(win, e);
-            advance(e, cand);
-            o += (e >> 8) & 255u;
-            // only the lanes that stay in the loop store here (their index is inside the block: no range test, no dump
-            // byte); the symbol that ENDS a block by filling coefficient 63 is stored below, once
-            if (o < 63u) la_st8(slot_b + (o ^ rot), v);
+            const int v1 = wp_value(win, e >> 23, e >> 28);
+            const uint32_t o1 = o + ((e >> 8) & 255u);
+            const int v2 = wp_value(win, e, (e >> 5) & 7u);
+            const uint32_t o2 = o1 + ((e >> 16) & 127u);
+            // symbol 1 ends the block (coefficient 63, EOB, or a run past the end): symbol 2, if the entry has one, is not
+            // this block's -- the window moves past symbol 1 only.  The lanes that stay in the loop are those whose LAST
+            // coefficient of this step lies inside the block; a coefficient that completes the block is stored below, once.
+            const bool d1 = o1 >= 63u;
+            const uint32_t a1 = d1 ? dump_b : slot_b + (o1 ^ rot);
+            const uint32_t a2 = (!d1 && o2 < 63u) ? slot_b + (o2 ^ rot) : dump_b;
+            la_st8(a2, v2);                                               // (an empty second half lands on symbol 1's byte first ...
+            la_st8(a1, v1);                                               //  ... LDS operations of a wave execute in order)
+            v = d1 ? v1 : v2;
+            o = d1 ? o1 : o2;
+            advance(d1 ? (e >> 23) : e, cand);
         }
         if (o == 63u) la_st8(slot_b + (63u ^ rot), v);
         if (act) {
-            // a block ends at index 63 exactly or by EOB (>= 127); in between = a run that walked past coefficient 63
-            if (o > 63u && o < 127u) err |= JD_ST_COEF;
+            // a block ends at index 63 exactly or by EOB (>= JD_WP_EOB_ADV); in between = a run that walked past coefficient 63
+            if (o > 63u && o < JD_WP_EOB_ADV) err |= JD_ST_COEF;
             wave_lds_order();
             const int b63 = la_i8(slot_b + (63u ^ rot));
             const bool wide = wcnt != 0 || wide_dc || (uint32_t)(b63 + 7) > 14u;

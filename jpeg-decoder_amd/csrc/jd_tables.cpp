@@ -163,6 +163,84 @@ int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool i
     return 0;
 }
 
+// Pair table of the byte-form writer (write_segments8; layout in jd_internal.h, JD_WP_*): an entry resolves the symbol
+// whose code starts the index bits and, when the CODE of the symbol after it also lies wholly inside them, that second
+// symbol too -- its magnitude bits may reach past the index, the decoder reads them from its 32-bit window.  At quality
+// 85 with the Annex-K tables two entries in three are pairs and a lookup resolves 1.4 symbols.  Never paired: a symbol
+// after EOB (the next block starts with another table), a symbol of magnitude category >= 8 (the decoder keeps its
+// high part through a rare path that knows one symbol per entry), and codes longer than the primary index.
+int jd_pack_lut32p(const uint8_t bits[16], const uint8_t* vals, int nvals, unsigned prim_bits, std::vector<uint32_t>& out) {
+    if (prim_bits < 8 || prim_bits > 12) return -1;
+    const unsigned sec_bits = 16u - prim_bits;
+    int count = 0;
+    for (int i = 0; i < 16; i++) count += bits[i];
+    if (count != nvals || nvals > 256) return -1;
+    struct Code { unsigned code, len, sym; };
+    std::vector<Code> codes;
+    {
+        unsigned code = 0; int k = 0;
+        for (unsigned len = 1; len <= 16; len++) {
+            for (int i = 0; i < bits[len - 1]; i++, k++) {
+                if (code >= (1u << len)) return -2;
+                codes.push_back({ code, len, vals[k] });
+                code++;
+            }
+            code <<= 1;
+        }
+    }
+    // (advance, size) of a run/size symbol; advance 0 = not a symbol the baseline decoder knows (Go: negative shift panic)
+    auto adv_of = [](unsigned sym) -> unsigned {
+        if (sym == 0x00) return JD_WP_EOB_ADV;
+        if ((sym & 15u) == 0 && (sym >> 4) != 15u) return 0;
+        return (sym >> 4) + 1u;
+    };
+    auto single = [&](unsigned sym, unsigned len) -> uint32_t {
+        const unsigned adv = adv_of(sym), size = sym & 15u;
+        if (!adv) return 0;
+        const unsigned sh = 32u - (len + size);                     // 1 .. 31
+        return sh | (adv << 8) | (sh << 23) | (size << 28);
+    };
+    const size_t base = out.size();
+    out.resize(base + (1u << prim_bits), 0);
+    for (const Code& c : codes) {
+        const uint32_t e1 = single(c.sym, c.len);
+        if (c.len <= prim_bits) {
+            const unsigned first = c.code << (prim_bits - c.len), n = 1u << (prim_bits - c.len);
+            const unsigned size1 = c.sym & 15u, bits1 = c.len + size1;
+            for (unsigned j = 0; j < n; j++) {
+                uint32_t e = e1;
+                if (e1 && c.sym != 0x00 && size1 < 8 && bits1 < prim_bits) {
+                    const unsigned rest = prim_bits - bits1, tail = (first + j) & ((1u << rest) - 1u);   // index bits behind symbol 1
+                    for (const Code& d : codes) {
+                        if (d.len > rest) break;                                   // (codes are in order of length)
+                        if ((tail >> (rest - d.len)) != d.code) continue;
+                        const unsigned adv2 = adv_of(d.sym), size2 = d.sym & 15u;
+                        if (adv2 && size2 < 8)
+                            e = (32u - (bits1 + d.len + size2)) | (size2 << 5) | (adv_of(c.sym) << 8) | (adv2 << 16) | ((32u - bits1) << 23) | (size1 << 28);
+                        break;
+                    }
+                }
+                out[base + first + j] = e;
+            }
+        } else {
+            const unsigned prefix = c.code >> (c.len - prim_bits);
+            uint32_t p = out[base + prefix];
+            if (!(p & 0x80000000u)) {
+                if (p != 0) return -2;
+                const size_t off = out.size() - base;
+                if (off >= 4096) return -3;
+                out.resize(out.size() + (1u << sec_bits), 0);
+                p = 0x80000000u | ((uint32_t)off << 16);                          // (adv1 byte 0: not a symbol)
+                out[base + prefix] = p;
+            }
+            const unsigned sub = (c.code << (16 - c.len)) & ((1u << sec_bits) - 1u), n = 1u << (16 - c.len);
+            for (unsigned j = 0; j < n; j++) out[base + ((p >> 16) & 0xFFFu) + sub + j] = e1;
+        }
+    }
+    for (size_t i = base; i < out.size(); i++) if (out[i] == 0) out[i] = JD_W32_NONE;
+    return 0;
+}
+
 // Symbol table for the progressive scans, laid out for a decoder that runs on the SCALAR unit and keeps the table in
 // vector registers (kp_scan): 7 rows of 64 dwords, dword l of a row = what lane l holds.
 //   rows 0-3  primary table indexed by the next 8 bits of the stream: code length << 8 | symbol; 0 = the code is longer

@@ -17,6 +17,8 @@ int jd_pack_lut_bits(const uint8_t bits[16], const uint8_t* vals, int nvals, boo
 // unit: advance of one coefficient in the [15:8] field -- 2 (bytes of int16 coefficients; EOB 254) or 1 (byte form; EOB 127)
 int jd_pack_lut32(const uint8_t bits[16], const uint8_t* vals, int nvals, bool is_dc, unsigned prim_bits, unsigned unit,
                   std::vector<uint32_t>& out);
+// AC pair table of the byte-form writer (JD_WP_* layout, jd_internal.h): up to two symbols per entry.
+int jd_pack_lut32p(const uint8_t bits[16], const uint8_t* vals, int nvals, unsigned prim_bits, std::vector<uint32_t>& out);
 // Symbol table for the progressive scans: the decoder needs the raw symbol there (run/size, EOBn), not a baseline
 // interpretation of it.  JD_PLUT_DWORDS dwords, laid out for kp_scan's scalar-unit decoder (jd_tables.cpp).
 int jd_pack_lut_lane(const uint8_t bits[16], const uint8_t* vals, int nvals, std::vector<uint32_t>& out);

@@ -110,6 +110,57 @@ static void check_table(const char* name, const uint8_t bits[16], const uint8_t*
     }
 }
 
+// Pair table of the byte-form writer (jd_pack_lut32p): a walk over pseudo-random bits, decoded the way write_segments8
+// does (both symbols of an entry, values by wp_value's arithmetic), must produce the single-symbol walk's sequence of
+// (advance, value, bits) -- and a fair share of the lookups must resolve two symbols.
+static int wp_value(uint32_t win, uint32_t off, uint32_t size) {
+    off &= 31u; size &= 31u;
+    int y = 0;                                                     // v_bfe_i32
+    if (size) { const uint32_t f = (win >> off) & ((1u << size) - 1u); y = (f >> (size - 1)) ? (int)f - (int)(1u << size) : (int)f; }
+    const uint32_t m = (1u << size) - 1u;
+    return y - (int)(m ^ (uint32_t)(y >> 31));
+}
+static void check_pairs(const char* name, const uint8_t bits[16], const uint8_t* vals, int nvals) {
+    for (unsigned pb : {9u, 10u}) {
+        std::vector<uint32_t> tp, t1;
+        CHECK(jd_pack_lut32p(bits, vals, nvals, pb, tp) == 0, "%s pack32p", name);
+        CHECK(jd_pack_lut32(bits, vals, nvals, false, pb, 1, t1) == 0, "%s pack32", name);
+        uint64_t rng = 0x2545F4914F6CDD1Dull;
+        std::vector<uint8_t> bitsv(1 << 17);
+        for (auto& b : bitsv) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; b = (uint8_t)((rng >> 11) & 1); }
+        auto win_at = [&](size_t pos) { uint32_t w = 0; for (int i = 0; i < 32; i++) w = (w << 1) | bitsv[(pos + i) % bitsv.size()]; return w; };
+        auto lookp = [&](uint32_t win) {
+            uint32_t e = tp[win >> (32 - pb)];
+            if ((int)e < 0 && ((e >> 8) & 255u) == 0) { const uint32_t so = (e >> 16) & 0xFFFu; e = so ? tp[so + ((win >> 16) & (0xFFFFu >> pb))] : JD_W32_NONE; if (((e >> 8) & 255u) == 0) e = JD_WP_SKIP; }
+            return e;
+        };
+        size_t p1 = 0, pp = 0;
+        unsigned lookups = 0, pairs = 0, symbols = 0;
+        while (pp < bitsv.size() - 64 && fails < 20) {
+            const uint32_t win = win_at(pp), e = lookp(win);
+            const unsigned n = ((e >> 16) & 127u) ? 2 : 1;
+            for (unsigned k = 0; k < n; k++) {
+                // the single-symbol writer's arithmetic on the same position
+                uint32_t w = look32(t1, win_at(p1), pb);
+                if (!w) w = 31u | (JD_W32_EOB_ADV8 << 8);                  // invalid code: one bit, end of block (both writers)
+                const uint32_t m = w >> 16, raw = (win_at(p1) >> (w & 31u)) & m;
+                const int v = (int)raw - (int)(raw <= (w >> 17) ? m : 0u);
+                const unsigned adv = (w >> 8) & 255u, nb = 32 - (w & 31u);
+                const int vp = k == 0 ? wp_value(win, e >> 23, e >> 28) : wp_value(win, e, (e >> 5) & 7u);
+                const unsigned ap = k == 0 ? (e >> 8) & 255u : (e >> 16) & 127u;
+                const unsigned endp = k == 0 ? 32 - ((e >> 23) & 31u) : 32 - (e & 31u);
+                CHECK(p1 - pp + nb == endp && adv == ap && v == vp, "%s pair table P=%u at bit %zu symbol %u: bits %zu/%u adv %u/%u value %d/%d", name, pb, pp, k, p1 - pp + nb, endp, adv, ap, v, vp);
+                p1 += nb; symbols++;
+                if (k == 0 && n == 2) CHECK(adv != JD_WP_EOB_ADV && (e >> 28) < 8, "%s pair table pairs behind EOB or a wide symbol", name);
+            }
+            if (n == 1) CHECK(((e >> 23) & 31u) == (e & 31u) && ((e >> 5) & 7u) == 0, "%s single entry %08x has a second half", name, e);
+            pp = p1; lookups++; pairs += n == 2;
+        }
+        if (pb == 10) printf("%s: pair table, %u symbols in %u lookups (%u pairs) on random bits\n", name, symbols, lookups, pairs);
+        CHECK(pairs * 4 > lookups, "%s: too few pairs (%u of %u)", name, pairs, lookups);
+    }
+}
+
 // Annex K.3 tables (ITU T.81)
 static const uint8_t dcl_bits[16] = {0,1,5,1,1,1,1,1,1,0,0,0,0,0,0,0}, dcl_vals[12] = {0,1,2,3,4,5,6,7,8,9,10,11};
 static const uint8_t dcc_bits[16] = {0,3,1,1,1,1,1,1,1,1,1,0,0,0,0,0}, dcc_vals[12] = {0,1,2,3,4,5,6,7,8,9,10,11};
@@ -135,6 +186,8 @@ int main() {
     check_table("dc-chroma", dcc_bits, dcc_vals, 12, true);
     check_table("ac-luma", acl_bits, acl_vals, 162, false);
     check_table("ac-chroma", acc_bits, acc_vals, 162, false);
+    check_pairs("ac-luma", acl_bits, acl_vals, 162);
+    check_pairs("ac-chroma", acc_bits, acc_vals, 162);
     // a table with a size-0 symbol that is neither EOB nor ZRL (the Go reference panics on it): entry must be invalid
     { uint8_t b[16] = {0,2,0}; uint8_t v[2] = {0x00, 0x30}; check_table("ac-bad-symbol", b, v, 2, false); }
     // malformed tables
