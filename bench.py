@@ -25,6 +25,7 @@ bands shard with no data-path collective.  `python bench.py --gpus N` with N > 1
 STARTS the N ranks itself (child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never touches
 the GPU), relays rank 0's line and exits with the worst child's code; under torch.distributed.run it is a rank.
 `--dry` replaces the GPU work by nothing at all (gloo backend, planning and rendezvous only): the launcher test on CPU.
+`--share-gpu` rehearses the N-rank path on a one-GPU box (all ranks on device 0, gloo): correctness, not speed.
 
 Rank 0 prints ONE JSON line.  `value` is metric (i) of SURVEY 8(d): inputs and outputs resident in HBM.  `roofline` is
 for the dominant stage (device time from hipEvents recorded inside the timed steps, on the stream the kernels run on);
@@ -89,8 +90,9 @@ def launch_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
     codes = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
+    for line in out0.decode().splitlines():                    # rank 0's JSON line (gloo prints a connection notice to stdout)
+        if line.startswith("{"):
+            print(line, flush=True)
     worst = max(codes, key=lambda c: (c != 0, abs(c)))
     return worst if 0 <= worst < 256 else 1
 
@@ -99,7 +101,7 @@ def launch_ranks(n, argv):
 class Rank:
     """what a rank knows about the job: its place, its device, the two collectives the bench uses"""
 
-    def __init__(self, dry):
+    def __init__(self, dry, share_gpu=False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,18 +109,23 @@ class Rank:
         import torch
         self.torch = torch
         self.dist = None
+        self.gpu = 0 if share_gpu else self.local_rank          # HIP device this rank decodes on
         if dry:
-            self.dev = torch.device("cpu")
+            self.dev = self.cdev = torch.device("cpu")
             if self.world > 1:
                 import torch.distributed as dist
                 dist.init_process_group("gloo")
                 self.dist = dist
         else:
-            torch.cuda.set_device(self.local_rank)
-            self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.gpu)
+            self.dev = torch.device("cuda", self.gpu)
+            self.cdev = torch.device("cpu") if share_gpu else self.dev   # where the barrier's / reductions' tensors live
             if self.world > 1:
                 import torch.distributed as dist
-                dist.init_process_group("nccl", device_id=self.dev)
+                if share_gpu:                                   # rehearsal on a one-GPU box: RCCL refuses two ranks on one device
+                    dist.init_process_group("gloo")
+                else:
+                    dist.init_process_group("nccl", device_id=self.dev)
                 self.dist = dist
 
     def barrier(self):
@@ -130,14 +137,14 @@ class Rank:
     def max_f(self, v):
         if self.dist is None:
             return float(v)
-        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.cdev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_i(self, v):
         if self.dist is None:
             return int(v)
-        t = self.torch.tensor([v], dtype=self.torch.int64, device=self.dev)
+        t = self.torch.tensor([v], dtype=self.torch.int64, device=self.cdev)
         self.dist.all_reduce(t)
         return int(t.item())
 
@@ -337,7 +344,7 @@ def run_resident(jd, R, wl, shard, args, headline):
         frames = [cuts[items[i]][0] for i in idx]
         lens = [cuts[items[i]][2] for i in idx]
         rgbs = [torch.empty((cuts[items[i]][4], w, 3), dtype=torch.uint8, device=R.dev) for i in idx]
-        b = jd.Batch(frames, lens, device=R.local_rank, external_io=True)
+        b = jd.Batch(frames, lens, device=R.gpu, external_io=True)
         for k, i in enumerate(idx):
             e = src[items[i]].clone()
             assert e.data_ptr() % 16 == 0
@@ -437,8 +444,8 @@ def run_resident(jd, R, wl, shard, args, headline):
         frames = [frame0] * per_slot
         passes = 3 if wl != "c5" else 6
         pc = pcie_rates(torch, R.dev)
-        ii, n_ii, ok_ii = end_to_end(jd, torch, files, frames, w, h, R.local_rank, False, passes, per_slot, want=want0)
-        iii, n_iii, ok_iii = end_to_end(jd, torch, files, frames, w, h, R.local_rank, True, passes, per_slot, want=want0)
+        ii, n_ii, ok_ii = end_to_end(jd, torch, files, frames, w, h, R.gpu, False, passes, per_slot, want=want0)
+        iii, n_iii, ok_iii = end_to_end(jd, torch, files, frames, w, h, R.gpu, True, passes, per_slot, want=want0)
         roof = pc["d2h"] * 1e9 / 3.0 / 1e6                      # MP/s if nothing but the RGB copy-back took time
         out["end_to_end"] = {"device_incl_pcie_MPs": round(ii, 1), "host_incl_parse_MPs": round(iii, 1),
                              "images_timed": n_ii, "batches_in_flight": 3, "images_per_batch": per_slot,
@@ -460,7 +467,7 @@ def run_pipeline(jd, R, wl, args):
     frames = [parsed[plan["items"][0][0]][0]] * per_slot
     passes = max(1, -(-n_mine // (3 * per_slot))) * args.steps
     R.barrier()
-    mps, n_img, _ = end_to_end(jd, R.torch, files, frames, w, h, R.local_rank, args.mode == "host", passes, per_slot)
+    mps, n_img, _ = end_to_end(jd, R.torch, files, frames, w, h, R.gpu, args.mode == "host", passes, per_slot)
     dt = R.max_f(n_img * w * h / (mps * 1e6))
     R.barrier()
     n_job = R.sum_i(n_img)
@@ -485,7 +492,7 @@ def run_progressive(jd, R, args):
     px = [f.width * f.height for f in (jd.parse_scans(d)[0] for d in files)]
     if R.dry:
         return {"dry": True, "files": len(files)} if R.rank == 0 else None
-    jd.decode_progressive_batch(files[:2], device=R.local_rank)             # warm-up (first launch of kp_scan)
+    jd.decode_progressive_batch(files[:2], device=R.gpu)             # warm-up (first launch of kp_scan)
     res, ok = {}, True
     for nb in (1, 64, 1024):
         grp = [files[i % len(files)] for i in range(nb)]
@@ -493,12 +500,12 @@ def run_progressive(jd, R, args):
         reps = 5 if nb == 1 else (2 if nb == 64 else 1)
         t0 = time.perf_counter()
         for _ in range(reps):
-            outs, status = jd.decode_progressive_batch(grp, device=R.local_rank)
+            outs, status = jd.decode_progressive_batch(grp, device=R.gpu)
         dt = (time.perf_counter() - t0) / reps
         ok = ok and all(s == 0 for s in status)
         res[str(nb)] = {"files": nb, "ms_per_call": round(dt * 1e3, 2), "MPs": round(gpx / dt / 1e6, 1)}
     # parity + CPU baseline on every distinct file (oracle: entropy + pixel time of the same files, 1 thread)
-    outs, _ = jd.decode_progressive_batch(files, device=R.local_rank)
+    outs, _ = jd.decode_progressive_batch(files, device=R.gpu)
     t_cpu = 0.0
     for d, got in zip(files, outs):
         o = orclib.OracleImage(d)
@@ -538,6 +545,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end sample of the default mode")
     ap.add_argument("--no-extra", action="store_true", help="--workload all: measure the headline only")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher, rendezvous (gloo) and planning only")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank decodes on device 0, gloo for the barrier "
+                                                             "(RCCL refuses two ranks on one device); the value then measures nothing")
     ap.add_argument("--dry-size", default="256x128", help="--dry: picture size used for c3 / c4 / c5 planning")
     args = ap.parse_args()
 
@@ -548,10 +557,10 @@ def main():
         dw, dh = (int(v) for v in args.dry_size.split("x"))
         for k in ("c3", "c4", "c5"):
             GEOM[k] = (dw, dh, GEOM[k][2])
-    R = Rank(args.dry)
+    R = Rank(args.dry, args.share_gpu)
     import jpeg_decoder_amd as jd
     if not args.dry:
-        jd.init([R.local_rank])
+        jd.init([R.gpu])
 
     headline_wl = "c3" if args.workload == "all" else args.workload
     extra = {}
