@@ -547,16 +547,18 @@ def main():
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher, rendezvous (gloo) and planning only")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank decodes on device 0, gloo for the barrier "
                                                              "(RCCL refuses two ranks on one device); the value then measures nothing")
-    ap.add_argument("--dry-size", default="256x128", help="--dry: picture size used for c3 / c4 / c5 planning")
+    ap.add_argument("--dry-size", default=None, help="picture size WxH used for c3 / c4 / c5 instead of the workloads' own "
+                                                      "(--dry: 256x128 unless given; otherwise a rehearsal, not a measurement)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # not under a launcher: be one (before anything touches the GPU)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
-    if args.dry:
-        dw, dh = (int(v) for v in args.dry_size.split("x"))
+    if args.dry or args.dry_size:
+        dw, dh = (int(v) for v in (args.dry_size or "256x128").split("x"))
         for k in ("c3", "c4", "c5"):
             GEOM[k] = (dw, dh, GEOM[k][2])
+            LABEL[k] += " -- REHEARSAL at %dx%d" % (dw, dh)
     R = Rank(args.dry, args.share_gpu)
     import jpeg_decoder_amd as jd
     if not args.dry:
