@@ -2065,11 +2065,20 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
 #pragma unroll
                     for (int kk = 0; kk < NK; kk++) {
                         const int k = NK * hh + kk;
-                        const f32x2 y = { (float)ys[2 * k], (float)ys[2 * k + 1] };
+                        // (the sums with a chroma product are plain v_add_f32 / v_sub_f32: as packed operations each
+                        // needed its product copied into both halves of a register pair first -- a v_mov per product and
+                        // pixel row, 512 per MCU -- and two plain adds cost no more issue cycles than one packed add)
+                        const float y0 = (float)ys[2 * k], y1 = (float)ys[2 * k + 1];
                         const f32x2 off = { 128.0f, 128.0f };
-                        R[kk] = (y + f32x2{ rc[k], rc[k] }) + off;
-                        G[kk] = ((y - f32x2{ gb[k], gb[k] }) - f32x2{ gr[k], gr[k] }) + off;
-                        B[kk] = (y + f32x2{ bc[k], bc[k] }) + off;
+                        float r0 = __fadd_rn(y0, rc[k]), r1 = __fadd_rn(y1, rc[k]);
+                        float g0 = __fsub_rn(y0, gb[k]), g1 = __fsub_rn(y1, gb[k]);
+                        float b0 = __fadd_rn(y0, bc[k]), b1 = __fadd_rn(y1, bc[k]);
+                        asm("" : "+v"(r0), "+v"(r1), "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1));   // (or hipcc packs them again)
+                        g0 = __fsub_rn(g0, gr[k]); g1 = __fsub_rn(g1, gr[k]);
+                        asm("" : "+v"(g0), "+v"(g1));
+                        R[kk] = f32x2{ r0, r1 } + off;
+                        G[kk] = f32x2{ g0, g1 } + off;
+                        B[kk] = f32x2{ b0, b1 } + off;
                     }
                     // fence: the values exist before the rounding mode changes
 #pragma unroll
