@@ -434,14 +434,13 @@ def run_resident(jd, R, wl, shard, args, headline):
             out["cpu_baseline"] = cpu_baseline(jd, w, h, args.quality, args.detail, t_first)
     for b, _, _ in batches:
         b.close()
-    files = [made[it[0]][0] for it in items[:min(n_mine, 384)]]
-    frame0 = parsed[items[0][0]][0]
     del batches, keep, src
     torch.cuda.empty_cache()
     if out is not None and want0 is not None and shard != "bands":
         per_slot = 2 if wl != "c5" else 128
+        files = [made[it[0]][0] for it in items[:min(n_mine, 384)]]
         files = [files[i % len(files)] for i in range(3 * per_slot)]
-        frames = [frame0] * per_slot
+        frames = [parsed[items[0][0]][0]] * per_slot
         passes = 3 if wl != "c5" else 6
         pc = pcie_rates(torch, R.dev)
         ii, n_ii, ok_ii = end_to_end(jd, torch, files, frames, w, h, R.gpu, False, passes, per_slot, want=want0)
