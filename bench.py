@@ -10,10 +10,13 @@ can then see the GPU busy; `--repeat 1` makes a step one pass).  Workloads (SURV
        474 MB of entropy-coded data, more than the 256 MB Infinity Cache); weak scaling.
        `--shard bands`: the SAME `--images` pictures for the whole job, each cut by jd_split_bands into one band of MCU
        rows per rank (restart-interval-range sharding); strong scaling
-  c4   the same images without restart markers (self-synchronising Huffman decode); weak scaling
+  c4   the same images without restart markers (self-synchronising Huffman decode), 64 per GPU per pass (the 16 distinct
+       pictures four times over, every image with its own copy of its data in HBM: the sync pass's launches amortise
+       their tails -- 245k / 260k / 268k MP/s at 16 / 32 / 64 images per pass); weak scaling
   c5   BASELINE's "batch of 10k 1920x1080 4:2:0": `--total` images (10000; `--distinct` 64 seeds cycled, every image
        with its own copy of its data in HBM) dealt over the ranks by jpeg_decoder_amd.shard_images and decoded in
-       per-rank batches of `--batch` (1000); strong scaling
+       per-rank batches of `--batch` (5000: measured 236k / 243k / 244k / 249k / 248k MP/s at 1000 / 2000 / 2500 / 5000 /
+       10000 per batch on one GPU -- fewer, larger launches); strong scaling
   prog the reference's four progressive (SOF2) files and the 14 libjpeg twins through jd_decode_scans_batch (SURVEY
        row N4), host memory in and out, at batch sizes 1 / 64 / 1024; one rank
 
@@ -280,23 +283,24 @@ def plan_workload(jd, R, wl, shard, args):
     """Which pictures this rank decodes.  -> dict(seeds, items, per_batch, scaling, parallelism); an item is
     (seed, band index or None).  Host-only: `--dry` runs exactly this."""
     if wl == "c5":
-        per_batch = args.batch or 1000
+        per_batch = args.batch or 5000
         distinct = args.distinct or 64
         plan = jd.plan_job(args.total, R.world, R.rank, per_batch, distinct)   # strong scaling: the job is `total` images
         items = [(s, None) for grp in plan for _, s in grp]
         return {"seeds": sorted(set(s for s, _ in items)), "items": items, "per_batch": per_batch, "scaling": "strong",
                 "parallelism": "whole images dealt over the GPUs (shard_images), no collective"}
-    per_batch = args.batch or args.images
-    distinct = min(args.distinct or 16, args.images)
+    n_images = args.images or (64 if wl == "c4" else 16)
+    per_batch = args.batch or n_images
+    distinct = min(args.distinct or 16, n_images)
     if shard == "bands":
         seeds = [i for i in range(distinct)]                    # the same pictures on every rank: the job is `images` pictures
         mine = jd.shard_bands(R.world, R.world, R.rank)         # band k of every picture -> rank k % world
-        items = [(seeds[i % distinct], k) for i in range(args.images) for k in mine]
+        items = [(seeds[i % distinct], k) for i in range(n_images) for k in mine]
         return {"seeds": seeds, "items": items, "per_batch": per_batch * max(1, len(mine)), "scaling": "strong",
                 "parallelism": "every picture cut into %d bands of MCU rows (jd_split_bands), band k on rank k (shard_bands), "
                                "no collective" % R.world}
     seeds = [R.rank * 100003 + i for i in range(distinct)]     # weak scaling: every rank its own pictures
-    items = [(seeds[i % distinct], None) for i in range(args.images)]
+    items = [(seeds[i % distinct], None) for i in range(n_images)]
     return {"seeds": seeds, "items": items, "per_batch": per_batch, "scaling": "weak",
             "parallelism": "whole images dealt over the GPUs (shard_images), no collective"}
 
@@ -532,8 +536,8 @@ def main():
                     help="c3: whole images per rank (weak scaling) or one band of every image per rank (strong scaling)")
     ap.add_argument("--mode", default="resident", choices=["resident", "e2e", "host"],
                     help="what the timed steps measure: (i) HBM-resident kernels, (ii) + PCIe both ways, (iii) + header parsing")
-    ap.add_argument("--images", type=int, default=16, help="c3/c4: images per GPU per pass (bands: images of the whole job)")
-    ap.add_argument("--batch", type=int, default=0, help="images per jd_batch (default: c3/c4 all of the pass's, c5 1000)")
+    ap.add_argument("--images", type=int, default=0, help="c3/c4: images per GPU per pass (default: c3 16, c4 64; bands: images of the whole job)")
+    ap.add_argument("--batch", type=int, default=0, help="images per jd_batch (default: c3/c4 all of the pass's, c5 5000)")
     ap.add_argument("--repeat", type=int, default=0, help="passes per counted step (0: as many as make the timed region about a second)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the rank's batches are dealt over (1: one after another)")
     ap.add_argument("--total", type=int, default=10000, help="c5: images in the whole job, dealt over the ranks")
