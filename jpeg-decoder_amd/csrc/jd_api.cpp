@@ -31,6 +31,10 @@ void jdk_launch_sync(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t w
 void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s);
 void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, int16_t* d_out, hipStream_t s);
+void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
+void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, hipStream_t s);
+void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s);
+void jdk_launch_fscan_index(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K, hipStream_t s);
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
@@ -279,7 +283,13 @@ struct jd_batch {
     uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
     size_t clear_bytes = 0;                   // d_status .. d_changed + 64 words
     unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; JdSubPfx* d_subpfx = nullptr; JdSubCk* d_subck = nullptr; uint4* d_sync_tot = nullptr;
-    uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr;
+    uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr, *d_pre_f = nullptr;
+    // single-decode path of the streams without restart markers (JD_IMG_FUSED, jd_internal.h)
+    uint2* d_loc = nullptr; uint32_t *d_chunk = nullptr, *d_guess = nullptr, *d_wl = nullptr, *d_falloc = nullptr, *d_fcount = nullptr;
+    uint32_t fkmax = 0, wg_f = 0;
+    bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
+    int fused_rounds = JD_F_ROUNDS;            // JD_DEBUG_FUSED_ROUNDS (0 .. JD_F_ROUNDS): fewer blind rounds, so that a test can
+                                               // drive jd_batch_wait's extra rounds
     // pinned host mirror of the descriptor block, followed by the read-back words (status per image, 64 sync flags)
     uint8_t* h_desc = nullptr; size_t desc_bytes = 0, pre_stride = 0;
     uint32_t *h_status = nullptr, *h_changed = nullptr;
@@ -289,7 +299,7 @@ struct jd_batch {
     uint32_t max_lut_bytes = 0, max_w_bytes = 0;
     uint32_t wg_k0 = 0, wg_iv = 0, wg_sync = 0, wg_wr = 0, wg_tile = 0;
     bool dirty = true, ran = false, any_uniform = false;
-    uint32_t k2_modes = 0;                                       // bit 2m + f: some image has sampling mode m and coefficient form f
+    uint32_t k2_modes = 0;                                       // bit 3m + f: some image has sampling mode m and coefficient form f (2 = staged)
     uint32_t coef_fmts = 0;                                      // bit 0: some image keeps int16 coefficients, bit 1: some use bytes
     int coef_form = 0;                                           // JD_COEF_FORM: 0 = choose per image, 8 / 16 = force
     hipStream_t stream = nullptr, last_stream = nullptr;
@@ -321,6 +331,7 @@ JdKernelArgs kernel_args(const jd_batch* b) {
     a.imgs = b->d_img; a.n_images = b->n; a.prefix = nullptr; a.stream = b->d_stream; a.coef = b->d_coef;
     a.lut = b->d_lut; a.status = b->d_status; a.stream_len = b->d_stream_len; a.interval_start = b->d_interval;
     a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.subpfx = b->d_subpfx; a.subck = b->d_subck; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
+    a.loc = b->d_loc; a.chunk = b->d_chunk; a.guess = b->d_guess; a.wl = b->d_wl; a.falloc = b->d_falloc; a.fcount = b->d_fcount; a.fkmax = b->fkmax;
     return a;
 }
 
@@ -336,23 +347,28 @@ int refresh(jd_batch* b, hipStream_t s) {
     // ... and a run still in flight on ANOTHER stream must not see its descriptors change under it
     if (b->ran && b->last_stream != s) HIPCHK(hipStreamSynchronize(b->last_stream));
     JdImg* himg = reinterpret_cast<JdImg*>(b->h_desc);
-    uint32_t* pre[5];
-    for (int k = 0; k < 5; k++) pre[k] = reinterpret_cast<uint32_t*>(b->h_desc + align_up((size_t)n * sizeof(JdImg), 256) + (size_t)k * b->pre_stride);
-    for (int k = 0; k < 5; k++) pre[k][0] = 0;
+    uint32_t* pre[6];
+    for (int k = 0; k < 6; k++) pre[k] = reinterpret_cast<uint32_t*>(b->h_desc + align_up((size_t)n * sizeof(JdImg), 256) + (size_t)k * b->pre_stride);
+    for (int k = 0; k < 6; k++) pre[k][0] = 0;
+    b->k2_modes = 0;
     for (int i = 0; i < n; i++) {
         JdImg& im = b->img[i];
         const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
         im.n_k0_chunks = stuffed ? (uint32_t)((im.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK) : 0;
         const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
-        const uint32_t nsw = im.restart_interval ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_OWN - 1) / JD_SYNC_OWN);
+        if (!b->fused) im.flags &= ~(uint32_t)JD_IMG_FUSED;
+        const bool fz = (im.flags & JD_IMG_FUSED) != 0;
+        const uint32_t nsw = (im.restart_interval || fz) ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_OWN - 1) / JD_SYNC_OWN);
+        b->k2_modes |= (fz ? 4u : (im.flags & JD_IMG_COEF8) ? 2u : 1u) << (3 * (im.ncomp == 1 ? 0 : im.hs + 2 * im.vs - 2));
         pre[0][i + 1] = pre[0][i] + im.n_k0_chunks;
         pre[1][i + 1] = pre[1][i] + (im.restart_interval ? (im.n_intervals + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES) : 0);
         pre[2][i + 1] = pre[2][i] + nsw;
         pre[3][i + 1] = pre[3][i] + (nsw * JD_SYNC_WG + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
         pre[4][i + 1] = pre[4][i] + im.n_tiles;
+        pre[5][i + 1] = pre[5][i] + (fz ? std::min(im.n_fwg, (nsub + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES)) : 0);
         himg[i] = im;
     }
-    b->wg_k0 = pre[0][n]; b->wg_iv = pre[1][n]; b->wg_sync = pre[2][n]; b->wg_wr = pre[3][n]; b->wg_tile = pre[4][n];
+    b->wg_k0 = pre[0][n]; b->wg_iv = pre[1][n]; b->wg_sync = pre[2][n]; b->wg_wr = pre[3][n]; b->wg_tile = pre[4][n]; b->wg_f = pre[5][n];
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc, b->desc_bytes, hipMemcpyHostToDevice, s));
     if (b->ev_desc) HIPCHK(hipEventRecord(b->ev_desc, s));
     b->desc_in_flight = true; b->last_stream = s;
@@ -383,10 +399,23 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
                 jdk_launch_sync(a, b->d_pre_sync, b->wg_sync, b->max_lut_bytes, 1, k, 0, s);
             jdk_launch_sync_spine(a, s);
         }
+        jdk_launch_fcold(a, b->d_pre_f, b->wg_f, b->max_lut_bytes, s);
         break;
     case ST_HUFF_WRITE:
         jdk_launch_write_subseq(a, b->d_pre_wr, b->wg_wr, b->max_w_bytes, b->coef_fmts, s);
         if (b->wg_wr && b->any_uniform) jdk_launch_dc_scan(a, s);
+        if (b->wg_f) {
+            // the writing decode from the blind guesses, then JD_F_ROUNDS rounds of "list the sub-sequences whose entry is
+            // not their predecessor's exit, decode those again" (the first redoes one in twelve, the rest next to nothing),
+            // a last check for jd_batch_wait, the prefix scan and the block index
+            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, s);
+            for (int r = 0; r < b->fused_rounds; r++) {
+                jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, r, s);
+                jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, r, s);
+            }
+            jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
+            jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, s);
+        }
         break;
     case ST_IDCT_COLOUR:
         jdk_launch_idct_colour(a, b->d_pre_tile, b->wg_tile, b->k2_modes, b->K, s);
@@ -397,8 +426,8 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
 }
 
 bool stage_is_empty(const jd_batch* b, int stage) {
-    return (stage == ST_HUFF_DRI && b->wg_iv == 0) || (stage == ST_HUFF_SYNC && b->wg_sync == 0) ||
-           (stage == ST_HUFF_WRITE && b->wg_wr == 0);
+    return (stage == ST_HUFF_DRI && b->wg_iv == 0) || (stage == ST_HUFF_SYNC && b->wg_sync == 0 && b->wg_f == 0) ||
+           (stage == ST_HUFF_WRITE && b->wg_wr == 0 && b->wg_f == 0);
 }
 
 void batch_release(jd_batch* b) {
@@ -439,12 +468,16 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     b->coef_form = env_int("JD_COEF_FORM", 0);                    // 8 / 16: force the coefficient form (tests); else per image
     if (b->coef_form != 8 && b->coef_form != 16) b->coef_form = 0;
     if (dev) { b->arena.base = dev->scratch; b->arena.cap = dev->scratch_bytes; }
+    // the single-decode path needs staging beyond the fixed block of jd_decode_resident: batches of their own only
+    b->fused = !dev && env_int("JD_NODRI_FUSED", 1) != 0;
+    b->fused_rounds = std::min(std::max(env_int("JD_DEBUG_FUSED_ROUNDS", JD_F_ROUNDS), 0), JD_F_ROUNDS);
 
     // ---- Huffman table sets, de-duplicated across the batch -----------------------------------------
     std::vector<uint16_t> lut;
     std::map<std::string, std::pair<uint32_t, uint32_t>> seen;   // serialised tables -> (offset, length)
     size_t ecs_own = 0, rgb_own = 0, stream = 0, coef = 0;
     uint32_t k0c = 0, ivb = 0, subb = 0, swb = 0;
+    size_t locn = 0;
     for (int i = 0; i < n_images; i++) {
         const jd_frame& f = frames[i];
         JdImg& im = b->img[i];
@@ -479,8 +512,10 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                 for (int k = 1; k < 64; k++) if (f.qt[f.comp[c].tq][k] < 2) { bytes = false; break; }
         } else if (b->coef_form == 16) bytes = false;
         if (bytes) im.flags |= JD_IMG_COEF8;
+        const bool fz = b->fused && bytes && f.restart_interval == 0;
+        if (fz) im.flags |= JD_IMG_FUSED;
         b->coef_fmts |= bytes ? 2u : 1u;
-        b->k2_modes |= (bytes ? 2u : 1u) << (2 * (f.ncomp == 1 ? 0 : g.hs + 2 * g.vs - 2));
+        b->k2_modes |= (fz ? 4u : bytes ? 2u : 1u) << (3 * (f.ncomp == 1 ? 0 : g.hs + 2 * g.vs - 2));
         const unsigned unit = bytes ? 1u : 2u;
         key.push_back((char)unit);
         for (int c = 0; c < f.ncomp; c++) {
@@ -543,10 +578,33 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
         b->own_ecs_off[i] = ecs_own; ecs_own += align_up(ecs_cap[i] + 16, 256);
         b->own_rgb_off[i] = rgb_own; rgb_own += align_up((size_t)f.width * 3 * f.height, 256);
         im.stream_off = stream; stream += align_up(JD_STREAM_FRONT + ecs_cap[i] + JD_STREAM_TAIL, 256);
-        im.coef_off = coef; coef += (size_t)im.n_mcus * im.bpm * 64;
+        im.n_subseq_cap = (uint32_t)(((uint64_t)ecs_cap[i] * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
+        im.coef_off = coef;
+        if (fz) {
+            // staging: every block + a part-filled chunk per sub-sequence + room for what wrong guesses decode (if that
+            // is ever not enough the batch falls back to the two-pass path, JD_ST_FOVF)
+            const uint64_t nb = (uint64_t)im.n_mcus * im.bpm;
+            uint64_t cap = nb + (uint64_t)JD_F_CHUNK * im.n_subseq_cap + nb / 4 + 64 * JD_F_CHUNK;
+            const int pct = env_int("JD_DEBUG_FUSED_CAP_PERCENT", 0);   // tests: staging of pct % of the blocks, to see the fallback
+            if (pct > 0) cap = std::max<uint64_t>(nb * (uint64_t)pct / 100, 4 * JD_F_CHUNK);
+            if (cap >= (1ull << 31)) { batch_release(b); return JD_E_TOO_LARGE; }
+            im.slot_cap = (uint32_t)cap;
+            im.loc_off = locn; locn += (size_t)nb;
+            im.n_fwg = (im.n_subseq_cap + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
+            coef += (size_t)std::max(cap, nb) * 64;           // (never less than the two-pass layout needs: the fallback uses it)
+            // chunk-table entries a sub-sequence can need: its shortest possible block is the shortest DC code plus the
+            // shortest AC code (an EOB, or whatever the table offers)
+            uint32_t minbits = 32;
+            for (int c = 0; c < f.ncomp; c++) {
+                uint32_t ld = 16, la = 16;
+                for (uint32_t l = 16; l >= 1; l--) { if (f.huff[0][f.comp[c].td].bits[l - 1]) ld = l; if (f.huff[1][f.comp[c].ta].bits[l - 1]) la = l; }
+                minbits = std::min(minbits, ld + la);
+            }
+            const uint32_t kmax = (JD_SUBSEQ_BITS / minbits + 1 + JD_F_CHUNK - 1) / JD_F_CHUNK + 1;
+            b->fkmax = std::max(b->fkmax, std::min<uint32_t>(kmax, JD_F_KMAX_LIMIT));
+        } else coef += (size_t)im.n_mcus * im.bpm * 64;
         k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);
         im.interval_base = ivb; ivb += im.n_intervals + 1;
-        im.n_subseq_cap = (uint32_t)(((uint64_t)ecs_cap[i] * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
         im.n_sync_wg = f.restart_interval ? 0 : (im.n_subseq_cap + JD_SYNC_OWN - 1) / JD_SYNC_OWN;
         im.subseq_base = subb; subb += f.restart_interval ? 0 : im.n_sync_wg * JD_SYNC_OWN;
         im.sync_wg_base = swb; swb += im.n_sync_wg;
@@ -560,7 +618,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     // ---- descriptor block: JdImg[n], then five prefixes of n + 1 words; read-back words follow in the pinned mirror ----
     const size_t img_bytes = align_up((size_t)n_images * sizeof(JdImg), 256);
     b->pre_stride = align_up((size_t)(n_images + 1) * sizeof(uint32_t), 256);
-    b->desc_bytes = img_bytes + 5 * b->pre_stride;
+    b->desc_bytes = img_bytes + 6 * b->pre_stride;
     const size_t lut_bytes = lut.size() * sizeof(uint16_t);
     const size_t pinned_need = b->desc_bytes + align_up((size_t)n_images * 4, 256) + 256 + (dev ? align_up(lut_bytes, 256) : 0);
 
@@ -575,9 +633,20 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     A(&b->d_coef, coef * sizeof(int16_t));
     A(&b->d_lut, lut_bytes);
     // status words and the sync pass's "changed" flags sit in one block: one clear per run instead of two
-    b->clear_bytes = align_up((size_t)n_images * 4, 256) + 64 * 4;
+    // (and the single-decode path's chunk counters and list lengths: cleared by the same memset)
+    const size_t st_words = align_up((size_t)n_images * 4, 256) / 4, fw = b->fkmax ? st_words : 0;
+    b->clear_bytes = (st_words + 64 + fw * (2 + JD_F_ROUNDS)) * 4;
     A(&b->d_status, b->clear_bytes);
-    if (rc == JD_OK) b->d_changed = b->d_status + (b->clear_bytes - 64 * 4) / 4;
+    if (rc == JD_OK) {
+        b->d_changed = b->d_status + st_words;
+        if (b->fkmax) { b->d_falloc = b->d_changed + 64; b->d_fcount = b->d_falloc + fw; }
+    }
+    if (b->fkmax) {
+        A(&b->d_loc, std::max<size_t>(locn, 1) * sizeof(uint2));
+        A(&b->d_chunk, (size_t)subb * b->fkmax * 4);
+        A(&b->d_guess, (size_t)subb * 4);
+        A(&b->d_wl, (size_t)subb * 4);
+    }
     A(&b->d_stream_len, (size_t)n_images * 4);
     A(&b->d_interval, (size_t)ivb * 4);
     A(&b->d_k0, ((size_t)k0c + 32) * 8);
@@ -588,8 +657,8 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     A(&b->d_sync_tot, (size_t)swb * sizeof(uint4));
     if (rc == JD_OK) {
         b->d_img = reinterpret_cast<JdImg*>(b->d_desc);
-        uint32_t** pre[5] = { &b->d_pre_k0, &b->d_pre_iv, &b->d_pre_sync, &b->d_pre_wr, &b->d_pre_tile };
-        for (int k = 0; k < 5; k++) *pre[k] = reinterpret_cast<uint32_t*>(b->d_desc + img_bytes + (size_t)k * b->pre_stride);
+        uint32_t** pre[6] = { &b->d_pre_k0, &b->d_pre_iv, &b->d_pre_sync, &b->d_pre_wr, &b->d_pre_tile, &b->d_pre_f };
+        for (int k = 0; k < 6; k++) *pre[k] = reinterpret_cast<uint32_t*>(b->d_desc + img_bytes + (size_t)k * b->pre_stride);
     }
     if (rc == JD_OK) {
         if (dev) {
@@ -687,23 +756,50 @@ int wait_on(jd_batch* b) {
     HIPCHK(hipMemcpyAsync(b->h_status, b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     b->desc_in_flight = false;
+    // The single-decode path ran out of staging (speculative decodes of a hostile stream): the batch goes through the
+    // two-pass path, from the top, and stays there.
+    if (b->wg_f) {
+        bool ovf = false;
+        for (int i = 0; i < b->n; i++) ovf = ovf || (b->h_status[i] & JD_ST_FOVF) != 0;
+        if (ovf) {
+            b->fused = false; b->dirty = true;
+            int rc = run_on(b, s); if (rc) return rc;
+            if (b->io_pending) { rc = enqueue_rgb_download(b); if (rc) return rc; }
+            return wait_on(b);
+        }
+    }
     const bool more = b->wg_sync && (b->sync_fixups == 0 || b->h_changed[b->sync_fixups]);
-    if (more) {
+    const bool more_f = b->wg_f && b->h_changed[32];
+    if (more || more_f) {
         const JdKernelArgs a = kernel_args(b);
         int guard = 0;
-        do {
+        if (more) do {
             HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
             jdk_launch_sync(a, b->d_pre_sync, b->wg_sync, b->max_lut_bytes, 1, 1, 0, s);
             HIPCHK(hipMemcpyAsync(b->h_changed, b->d_changed, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
         } while (b->h_changed[1] && ++guard < 100000);
+        // single-decode path: the last check left a list; decode it, check again, until a check finds nothing
+        guard = 0;
+        if (more_f) do {
+            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, JD_F_ROUNDS, s);
+            HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
+            HIPCHK(hipMemsetAsync(b->d_fcount + (size_t)JD_F_ROUNDS * b->n, 0, (size_t)b->n * sizeof(uint32_t), s));
+            jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
+            HIPCHK(hipMemcpyAsync(b->h_changed, b->d_changed, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        } while (b->h_changed[32] && ++guard < 100000);
         // status bits and everything downstream of the sync records are recomputed
         HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));
         jdk_launch_k0(a, b->d_pre_k0, b->wg_k0, s);             // restores K0's status bits (idempotent)
         jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, b->coef_fmts, s);
-        jdk_launch_sync_spine(a, s);
-        int rc = enqueue_stage(b, ST_HUFF_WRITE, s); if (rc) return rc;
-        rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
+        if (b->wg_sync) {
+            jdk_launch_sync_spine(a, s);
+            jdk_launch_write_subseq(a, b->d_pre_wr, b->wg_wr, b->max_w_bytes, b->coef_fmts, s);
+            if (b->wg_wr && b->any_uniform) jdk_launch_dc_scan(a, s);
+        }
+        jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, s);
+        int rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
         if (b->io_pending) { rc = enqueue_rgb_download(b); if (rc) return rc; }
         HIPCHK(hipMemcpyAsync(b->h_status, b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -100,17 +100,37 @@ enum {
     JD_ST_TRUNC = 1u << 5,       // data ended early / interval overrun
     JD_ST_SYNC = 1u << 6,        // sync result inconsistent
     JD_ST_COUNT = 1u << 7,       // decoded block count != expected
-    JD_ST_SAMPLE = 1u << 8       // a post-IDCT chroma sample left int16 (K2; reported last: a damaged stream that
+    JD_ST_SAMPLE = 1u << 8,      // a post-IDCT chroma sample left int16 (K2; reported last: a damaged stream that
                                  // already earned another bit usually decodes to such garbage as well)
+    JD_ST_FOVF = 1u << 9         // single-decode path (k1f_*): the staging of a batch ran out (only speculative decodes of a
+                                 // hostile stream can ask for that much); never reported: the host decodes the batch again
+                                 // through the two-pass path
 };
 
 enum {
     JD_IMG_UNSTUFFED_INPUT = 1u,   // K0 is skipped, host filled stream + interval table
     JD_IMG_UNIFORM_TABLES = 2u,    // every component uses the same DC and the same AC table: the sync pass ignores the
                                    // block-in-MCU phase, the writer stores DC differences, k1_dc_scan predicts
-    JD_IMG_COEF8 = 4u              // coefficients travel from the Huffman writer to K2 as bytes: a 64-byte block in the low
+    JD_IMG_COEF8 = 4u,             // coefficients travel from the Huffman writer to K2 as bytes: a 64-byte block in the low
                                    // plane, the rare wide block's high parts in the high plane (write_segments8)
+    JD_IMG_FUSED = 8u              // no DRI, byte form: the single-decode path (k1f_*, below) instead of k1_sync + k1_write_subseq
 };
+
+// ---- single-decode path for streams without restart markers (k1f_*) --------------------------------------------------
+// The two-pass path decodes every bit 2.6 times (blind pass, counting pass, corrections, writing pass) because a block's
+// place in the coefficient array is a prefix sum over everything before it.  Here the WRITING decode runs first, on a
+// guessed entry state, into STAGING: slots of 64 bytes handed out in chunks of JD_F_CHUNK to the sub-sequence that asks
+// (one atomic per wave and 16 block steps), DC values relative to the sub-sequence's start.  Lanes whose guess turns out
+// wrong (one in twelve) decode again into their own chunks; a scan over the per-sub-sequence counts then gives every
+// block its index, and k1f_index writes, per block, where it lives and what to add to its DC (JdKernelArgs::loc) -- K2
+// reads coefficients through that.  Decodes per bit: 0.5 (blind) + 1 + 0.1.
+// Sub-sequence state here: the first block START at or after a sub-sequence's end, as [15:0] its bit offset past that
+// end, [23:16] its block-in-MCU index.
+#define JD_F_CHUNK 16u
+#define JD_F_ROUNDS 3              // re-decode rounds enqueued blindly; jd_batch_wait adds more while the last check finds work
+#define JD_F_KMAX_LIMIT 260u       // chunk-table entries per sub-sequence never exceed (4096 / 1 + 63) / 16
+#define JD_FSTATE(rel, c) (0x80000000u | ((rel) > 0xFFFFu ? 0xFFFFu : (rel)) | ((c) << 16))
+
 
 struct JdImg {
     const uint8_t* ecs;          // stuffed ECS (device)
@@ -138,6 +158,9 @@ struct JdImg {
     uint32_t w_ac_bits;          // primary index bits of the AC writer tables
     uint64_t stream_off;         // byte offset of this image's region in the unstuffed buffer
     uint64_t coef_off;           // int16 offset in the coefficient buffer
+    uint64_t loc_off;            // JD_IMG_FUSED: first entry of this image's blocks in JdKernelArgs::loc
+    uint32_t slot_cap;           // JD_IMG_FUSED: staging slots of this image (low plane: slot_cap x 64 B, then the high plane)
+    uint32_t n_fwg;              // JD_IMG_FUSED: workgroups of 64 * JD_W_WAVES lanes that cover its sub-sequences (capacity)
     uint8_t q[3][64];            // quantisation table per component, natural order
 };
 
@@ -205,5 +228,13 @@ struct JdKernelArgs {
     JdSubCk* subck;              // per sub-sequence: checkpoints of its first full decode
     uint4* sync_tot;             // per sync workgroup: (block starts, dc0, dc1, dc2) totals -> exclusive prefix after spine
     uint32_t* changed;           // sync: set when a workgroup's exit state changed
+    // single-decode path (JD_IMG_FUSED)
+    uint2* loc;                  // per block: (staging slot, DC base of its component at its sub-sequence's start)
+    uint32_t* chunk;             // per sub-sequence: fkmax chunk numbers (chunk k holds its blocks 16 k .. 16 k + 15)
+    uint32_t* guess;             // per sub-sequence: blind guess of its exit state
+    uint32_t* wl;                // per image (at subseq_base): sub-sequences to decode again
+    uint32_t* falloc;            // per image: chunks handed out
+    uint32_t* fcount;            // [JD_F_ROUNDS + 1][n_images]: length of the re-decode list of each round
+    uint32_t fkmax;
 };
 

@@ -711,9 +711,21 @@ __device__ __forceinline__ void write_segments(const JdKernelArgs& a, const JdIm
 // A block leaves as ONE 64-byte store instruction's worth (4 lanes x 16 B, non-temporal) as soon as it is complete.  (A
 // first version held the even block of a 128-byte line in registers until its partner was ready, as the int16 form does
 // with half blocks: 32 more VGPRs, spills at four waves per SIMD, and 12 % slower than two half-line stores.)
-template <bool NT>
+// FUSED (the single-decode path of streams without restart markers, jd_internal.h): the segment is a sub-sequence given by
+// BITS -- the lane decodes the blocks that start in [sg.start_bit, sg.end_bit), however many they are -- the blocks go to
+// staging slots (chunks of JD_F_CHUNK, handed out as the walk reaches them), DC values are relative to the segment's start
+// and errors are recorded with the block they happened in instead of raised (a speculative decode of garbage is not an
+// error of the image): the lane's results are its JdSub record.
+struct FusedSeg {
+    bool valid;              // the lane has a sub-sequence
+    uint32_t c0;             // block-in-MCU index of its first block
+    uint32_t entry;          // the entry state it decodes from (recorded for the next check)
+    uint32_t old_chunks;     // chunks an earlier decode of the sub-sequence already owns
+    uint32_t gsub;           // index of its record and chunk row (subseq_base + s)
+};
+template <bool NT, bool FUSED = false>
 __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
-                                                const Segment& sg, uint32_t slen, uint32_t err) {
+                                                const Segment& sg, uint32_t slen, uint32_t err, const FusedSeg* fs = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lbase = lds_abs_base();
@@ -756,32 +768,41 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     uint32_t npend = 0;
 
     int p0 = sg.p0, p1 = sg.p1, p2 = sg.p2;
-    uint32_t c = sg.nblk ? sg.blk0 % bpm : 0u;
+    uint32_t c = FUSED ? fs->c0 : (sg.nblk ? sg.blk0 % bpm : 0u);
     uint32_t bad = 0;
     uint32_t nsteps = sg.nblk;
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nsteps, d, 64); nsteps = t > nsteps ? t : nsteps; }
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(nsteps, d, 64); nsteps = t > nsteps ? t : nsteps; }
+    }
     const uint32_t nblocks = im.n_mcus * bpm;
     uint8_t* const lo_plane = reinterpret_cast<uint8_t*>(a.coef + im.coef_off);
     typedef __attribute__((address_space(1))) uint8_t g_u8;
-    g_u8* const hi_plane = (g_u8*)(lo_plane + (uint64_t)nblocks * 64u);
+    g_u8* const hi_plane = (g_u8*)(lo_plane + (uint64_t)(FUSED ? im.slot_cap : nblocks) * 64u);
+    // FUSED: chunk of the current 16 block steps (this lane's, and those of the four lanes whose blocks it helps to flush),
+    // blocks decoded, step of the first error, "ran out of chunk-table entries"
+    uint32_t cur_chunk = 0, f_chunk[4] = { 0, 0, 0, 0 }, my_nblk = 0, err_st = 0xFFFFu, err_first = 0;
+    bool stopped = false;
+    uint32_t* const ctab = FUSED ? a.chunk + (uint64_t)fs->gsub * a.fkmax : nullptr;
 
     // flush plan: a block leaves as 64 bytes written by 4 lanes (16 B each) of one store instruction; in pass q lanes
     // 4t' .. 4t'+3 move the block of lane t = 16q + (lane >> 2)
     const uint32_t part = lane & 3u;
     uint32_t blk_first = sg.nblk ? sg.blk0 : 0xFFFFFFFFu;
+    uint32_t f_end[4] = { 0, 0, 0, 0 }, f_off[4] = { 0, 0, 0, 0 };
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(blk_first, d, 64); blk_first = t < blk_first ? t : blk_first; }
-    blk_first = __builtin_amdgcn_readfirstlane(blk_first == 0xFFFFFFFFu ? 0u : blk_first);
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = __shfl_xor(blk_first, d, 64); blk_first = t < blk_first ? t : blk_first; }
+        blk_first = __builtin_amdgcn_readfirstlane(blk_first == 0xFFFFFFFFu ? 0u : blk_first);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t t = q * 16u + (lane >> 2);
+            f_end[q] = __shfl(sg.nblk, t, 64);
+            const uint32_t tb = __shfl(sg.blk0, t, 64);
+            f_off[q] = f_end[q] ? (tb - blk_first) * 64u + part * 16u : 0u;
+        }
+    } else blk_first = 0;
     uint8_t* const wave_dst = lo_plane + (uint64_t)blk_first * 64u;
-    uint32_t f_end[4], f_off[4];
-#pragma unroll
-    for (uint32_t q = 0; q < 4; q++) {
-        const uint32_t t = q * 16u + (lane >> 2);
-        f_end[q] = __shfl(sg.nblk, t, 64);
-        const uint32_t tb = __shfl(sg.blk0, t, 64);
-        f_off[q] = f_end[q] ? (tb - blk_first) * 64u + part * 16u : 0u;
-    }
     const uint32_t f_src = wbase + (lane >> 2) * 64u + ((part ^ ((lane >> 2) & 3u)) << 4);   // + q * 1024
     auto quad_index = [&](uint32_t xb) { const uint32_t q = qbase + ((xb - rot) >> 4); return q < qmax ? q : qmax; };
     auto request = [&](bool want) {
@@ -815,18 +836,20 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         w0 = stay ? w0 : w1; w1 = stay ? w1 : nxt; nxt = stay ? nxt : cand;
         rpb += stay ? 0u : four;
     };
-    auto flush = [&](uint32_t st) {
+    auto flush = [&](uint32_t st, uint64_t am) {                          // am (FUSED): the lanes that decoded a block in this step
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
             const uint4 h = la_u4(f_src + q * 1024u);
             la_st4(f_src + q * 1024u, make_uint4(0, 0, 0, 0));
-            if (st < f_end[q]) {
+            if (FUSED ? ((am >> (q * 16u + (lane >> 2))) & 1ull) != 0 : st < f_end[q]) {
                 jd_u32x4 t; t.x = h.x; t.y = h.y; t.z = h.z; t.w = h.w;
-                jd_u32x4* at = reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)st * 64u);
+                jd_u32x4* at = FUSED ? reinterpret_cast<jd_u32x4*>(lo_plane + ((uint64_t)f_chunk[q] * JD_F_CHUNK + (st & (JD_F_CHUNK - 1u))) * 64u + part * 16u)
+                                     : reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)st * 64u);
                 if (NT) __builtin_nontemporal_store(t, at); else *at = t;
             }
         }
     };
+    auto cur_pos = [&]() { const uint32_t rp = (rpb - rot) >> 2; return ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - (sh & 31u)); };
     // The high plane of a wide block.  The symbol loop keeps the high parts of up to four coefficients of magnitude
     // category >= 8 (position << 8 | high part, 16 bits each, in wl0 / wl1); with more than four the block is decoded ...
     auto wide_from_list = [&](uint32_t blk, int pred, int b63, uint32_t l0, uint32_t l1, uint32_t cnt) -> uint32_t {
@@ -902,8 +925,37 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     // and stores its value's low byte at the new index when that is inside the block (else to the dump byte).
     const uint32_t idle = 1u << 20;
 #pragma unroll 1
-    for (uint32_t st = 0; st < nsteps; st++) {
-        const bool act = st < sg.nblk;                                    // this lane decodes block st of its segment at step st
+    for (uint32_t st = 0; FUSED || st < nsteps; st++) {
+        bool act = st < sg.nblk;                                          // this lane decodes block st of its segment at step st
+        uint64_t act_mask = 0;
+        if constexpr (FUSED) {
+            act = fs->valid && !stopped && cur_pos() < sg.end_bit;        // a block that STARTS inside the sub-sequence is its own
+            act_mask = __builtin_amdgcn_ballot_w64(act);
+            if (act_mask == 0) break;
+            if ((st & (JD_F_CHUNK - 1u)) == 0u) {                         // (wave-uniform) the next 16 blocks need a chunk
+                const uint32_t k = st / JD_F_CHUNK;
+                if (act && k >= a.fkmax) { stopped = true; act = false; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
+                const bool have = k < fs->old_chunks;
+                uint32_t ch = (act && have) ? ctab[k] : 0u;
+                const uint64_t need = __builtin_amdgcn_ballot_w64(act && !have);
+                if (need) {                                               // one atomic per wave
+                    const uint32_t first = (uint32_t)__builtin_ctzll(need);
+                    uint32_t base = 0;
+                    if (lane == first) base = atomicAdd(a.falloc + img, (uint32_t)__popcll(need));
+                    base = (uint32_t)__shfl((int)base, (int)first, 64);
+                    if (act && !have) {
+                        ch = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                        if ((ch + 1u) * JD_F_CHUNK > im.slot_cap) { ch = 0; stopped = true; act = false; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
+                        else ctab[k] = ch;
+                    }
+                }
+                cur_chunk = ch;
+                act_mask = __builtin_amdgcn_ballot_w64(act);
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) f_chunk[q] = (uint32_t)__shfl((int)cur_chunk, (int)(q * 16u + (lane >> 2)), 64);
+            }
+            my_nblk += act ? 1u : 0u;
+        }
         request(act);
         wave_lds_order();
         const uint32_t comp = c < nl ? 0u : c - nl + 1u;
@@ -978,20 +1030,42 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             const bool wide = wcnt != 0 || wide_dc || (uint32_t)(b63 + 7) > 14u;
             uint32_t low4 = dchi;
             if (__builtin_expect(wide, 0)) {
-                if (wcnt <= 4u) low4 = wide_from_list(sg.blk0 + st, dcv, b63, wl0, wl1, wcnt);
+                const uint32_t wblk = FUSED ? cur_chunk * JD_F_CHUNK + (st & (JD_F_CHUNK - 1u)) : sg.blk0 + st;
+                if (wcnt <= 4u) low4 = wide_from_list(wblk, dcv, b63, wl0, wl1, wcnt);
                 else {
                     const uint32_t rp = (rpb0 - rot) >> 2;
                     const uint32_t pos = ((qbase * 4u + rp - 3u) - 4u) * 32u + (32u - sh0);
-                    low4 = wide_block(pos, dcb, acb, sg.blk0 + st, dcv);
+                    low4 = wide_block(pos, dcb, acb, wblk, dcv);
                 }
             }
             la_st8(slot_b + (63u ^ rot), (int)((wide ? 0x80u : ((uint32_t)b63 << 4)) | low4));
         }
         commit();
         wave_lds_order();
-        flush(st);
+        flush(st, act_mask);
         wave_lds_order();
         if (act) c = (c + 1u == bpm) ? 0u : c + 1u;
+        if constexpr (FUSED) {
+            const uint32_t now = err | (bad ? (uint32_t)JD_ST_HUFF : 0u);
+            if (now != 0u && err_st == 0xFFFFu) { err_st = st; err_first = now; }
+        }
+    }
+    if constexpr (FUSED) {
+        if (fs->valid) {
+            JdSub r;
+            const uint32_t pos = cur_pos();
+            r.entry = fs->entry;
+            r.exit = JD_FSTATE(pos > sg.end_bit ? pos - sg.end_bit : 0u, c);
+            r.nstart = my_nblk;
+            // what went wrong: in all its blocks [7:0], in the first block that had an error [15:8], which block that was
+            // [31:16] (the blocks behind the frame's last are garbage decoded from padding: their errors are nobody's)
+            r.first = ((err | (bad ? (uint32_t)JD_ST_HUFF : 0u)) & 0xFFu) | ((err_first & 0xFFu) << 8) | (err_st << 16);
+            r.dc[0] = p0; r.dc[1] = p1; r.dc[2] = p2;
+            const uint32_t nch = (my_nblk + JD_F_CHUNK - 1u) / JD_F_CHUNK;
+            r.pad = nch > fs->old_chunks ? nch : fs->old_chunks;
+            a.sub[fs->gsub] = r;
+        }
+        return;
     }
     if (sg.nblk) {
         if (bad) err |= JD_ST_HUFF;
@@ -1064,7 +1138,8 @@ __device__ __forceinline__ int* lds_int(uint32_t off) { return reinterpret_cast<
 #endif
 // MODE 0 = COLD (above); 1 = a sub-sequence's first full decode: records its checkpoints (JdSubCk, taken at block
 // starts); 2 = a later decode from a corrected entry state: stops at the first checkpoint whose state it reproduces and
-// completes its counts from the record.
+// completes its counts from the record.  3 = the blind decode of the single-decode path (k1f_cold): as 0, but it walks on to
+// the first block START past the sub-sequence's end and reports that (JD_FSTATE).
 __device__ __forceinline__ uint32_t ck_state(int left, uint32_t c, uint32_t z) { return ((uint32_t)left << 12) | (c << 8) | z; }
 // one checkpoint = two whole 16-byte non-temporal stores (stores of parts of a line make L2 fetch the line first)
 __device__ __forceinline__ void ck_store(JdCkEntry* e, uint32_t state, uint32_t nstart, int d0, int d1, int d2) {
@@ -1078,7 +1153,7 @@ template <int MODE>
 __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, const uint16_t* __restrict__ lutg,
                                             uint32_t s, uint32_t entry, uint32_t sbits, bool run, JdSub& rec,
                                             JdSubCk* __restrict__ ck = nullptr, bool use_ck = false) {
-    constexpr bool COLD = MODE == 0;
+    constexpr bool COLD = MODE == 0 || MODE == 3;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ring_l = JD_SY_RINGS + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * JD_SPEC_RING_BYTES + lane * 4u;
     auto ring_at = [&](uint32_t xb) { return lds_u32(ring_l | (xb & (JD_SPEC_RING_BYTES - 1u))); };
@@ -1147,7 +1222,8 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     uint32_t tgt = 0, tj = 0;                                             // MODE 2: pending checkpoint's state and index
     int matched = -1;
     if (MODE == 2 && run && use_ck) tgt = ck->e[0].state;
-    while (left > 0) {
+    // (MODE 3 gives up a sub-sequence's length past the end: garbage that never completes a block is just a wrong guess)
+    while (left > 0 || (MODE == 3 && z != 0u && left > -(int)JD_SUBSEQ_BITS)) {
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up();
         const uint32_t cand = ring_at(rpb);
         const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
@@ -1221,7 +1297,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     wave_lds_order();
     if (run) {
         rec.entry = entry;
-        rec.exit = pack_state((uint32_t)(-left), c, z);
+        rec.exit = MODE == 3 ? JD_FSTATE((uint32_t)(-left), c) : pack_state((uint32_t)(-left), c, z);
         rec.nstart = nstart;
         if (MODE == 2 && matched >= 0) rec.nstart += ck->e[JD_CK_N].nstart - ck->e[matched].nstart;   // (the recorded decode's block starts from here on)
         rec.first = rec.nstart ? (end - start) - first + (entry & 0xFFu) : 0u;   // bit offset from the sub-sequence start
@@ -1366,7 +1442,7 @@ __global__ __launch_bounds__(256) void k1_sync_spine(JdKernelArgs a) {
     __shared__ uint32_t tmp[16];
     const int img = blockIdx.x;
     const JdImg& im = a.imgs[img];
-    if (im.restart_interval != 0) return;
+    if (im.restart_interval != 0 || (im.flags & JD_IMG_FUSED)) return;
     const uint32_t sbits = a.stream_len[img] * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     uint32_t nwg = (nsub + JD_SYNC_OWN - 1u) / JD_SYNC_OWN;
@@ -1426,6 +1502,169 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1_write_subseq(JdKernelAr
     }
     if constexpr (C8) write_segments8<true>(a, im, img, lut_bytes, sg, slen, err);   // (uniform-table images keep int16)
     else write_segments<true>(a, im, img, lut_bytes, sg, slen, err, uniform);
+}
+
+// ================================================================================================================
+// Single-decode path of streams without restart markers (JD_IMG_FUSED; the scheme is described in jd_internal.h).
+//   k1f_cold    blind decode of the last JD_COLD_BITS of every sub-sequence -> guess[s]: where the first block past its end
+//               starts and which block of the MCU it is (11 guesses in 12 are right)
+//   k1f_write   round < 0: every sub-sequence decodes and WRITES from guess[s - 1];  round >= 0: the sub-sequences on
+//               the round's list decode again from their predecessor's recorded exit state
+//   k1f_check   lists the sub-sequences whose entry state is not their predecessor's exit state
+//   k1f_scan    exclusive prefix of the block counts and DC sums over an image's sub-sequences
+//   k1f_index   per block: its staging slot and the DC base of its component; raises the errors of blocks that exist
+// Lane L of image-relative workgroup w (64 * JD_W_WAVES lanes) is sub-sequence w * 64 * JD_W_WAVES + L.
+// ================================================================================================================
+#define JD_F_LANES (64u * JD_W_WAVES)
+
+__global__ __launch_bounds__(JD_SYNC_WG, 6) void k1f_cold(JdKernelArgs a) {
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    if (!(im.flags & JD_IMG_FUSED)) return;
+    const uint32_t lw = blockIdx.x - a.prefix[img];
+    const uint32_t slen = a.stream_len[img];
+    const uint32_t sbits = slen * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    if (lw * JD_F_LANES + 1u >= nsub) return;                  // (the last sub-sequence's exit is nobody's entry)
+    const ImgK ik = load_imgk(im);
+    if (threadIdx.x < 16u) {
+        const uint32_t cc = threadIdx.x < ik.bpm ? threadIdx.x : 0u;
+        const uint32_t comp = cc < ik.nl ? 0u : cc - ik.nl + 1u;
+        const uint32_t d = JD_SY_LUT + sel3(comp, im.sdc[0], im.sdc[1], im.sdc[2]) * 2u, ac = JD_SY_LUT + sel3(comp, im.sac[0], im.sac[1], im.sac[2]) * 2u;
+        *reinterpret_cast<uint32_t*>(dyn_lds + JD_SY_CTAB + threadIdx.x * 4u) = (d >> 2) | ((ac >> 2) << 15) | (comp << 30);
+    }
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds + JD_SY_LUT), a.lut + im.lut_off + im.lut_len, im.s_len);   // sync twin set
+    const uint4* Q = reinterpret_cast<const uint4*>(a.stream + im.stream_off);
+    const uint32_t qmax = (JD_STREAM_FRONT + slen + JD_STREAM_TAIL) / 16u - 1u;
+#pragma unroll 1
+    for (uint32_t h = 0; h < JD_F_LANES / JD_SYNC_WG; h++) {
+        const uint32_t s = lw * JD_F_LANES + h * JD_SYNC_WG + threadIdx.x;
+        if (__builtin_amdgcn_readfirstlane(lw * JD_F_LANES + h * JD_SYNC_WG + (threadIdx.x & ~63u)) + 1u >= nsub) continue;   // wave-uniform
+        const bool run = s + 1u < nsub;
+        JdSub rec; rec.entry = rec.exit = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0; rec.pad = 0;
+        spec_decode<3>(ik, Q, qmax, a.lut + im.lut_off, run ? s : 0u, pack_state(0, 0, 0), sbits, run, rec);
+        if (run) a.guess[im.subseq_base + s] = rec.exit;
+    }
+}
+
+__global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, uint32_t lut_bytes, int round) {
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    if (!(im.flags & JD_IMG_FUSED)) return;
+    const uint32_t lw = blockIdx.x - a.prefix[img];
+    const uint32_t slen = a.stream_len[img];
+    const uint32_t sbits = slen * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t L = lw * JD_F_LANES + threadIdx.x;
+    const uint32_t n_todo = round < 0 ? nsub : a.fcount[(uint32_t)round * (uint32_t)a.n_images + (uint32_t)img];
+    if (lw * JD_F_LANES >= n_todo) return;                      // whole workgroup idle (uniform)
+    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
+    FusedSeg fs; fs.valid = L < n_todo; fs.c0 = 0; fs.entry = JD_FSTATE(0u, 0u); fs.old_chunks = 0; fs.gsub = im.subseq_base;
+    Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
+    if (fs.valid) {
+        uint32_t s = L;
+        if (round >= 0) {
+            s = a.wl[im.subseq_base + L];
+            fs.old_chunks = a.sub[im.subseq_base + s].pad;
+            fs.entry = a.sub[im.subseq_base + s - 1u].exit;     // (the list never holds sub-sequence 0)
+        } else if (s) fs.entry = a.guess[im.subseq_base + s - 1u];
+        fs.gsub = im.subseq_base + s;
+        const uint32_t c0 = (fs.entry >> 16) & 0xFFu;
+        fs.c0 = c0 < im.bpm ? c0 : 0u;
+        sg.end_bit = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
+        sg.start_bit = s * JD_SUBSEQ_BITS + (fs.entry & 0xFFFFu);
+        if (sg.start_bit > sbits) sg.start_bit = sbits;          // (a block cannot start past the data; the walk then has nothing to do)
+    }
+    write_segments8<true, true>(a, im, img, lut_bytes, sg, slen, 0u, &fs);
+}
+
+// round = the list to fill (0 .. JD_F_ROUNDS; the last one is only counted: a.changed[32] tells the host that blind rounds
+// were not enough)
+__global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_check(JdKernelArgs a, int round) {
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    if (!(im.flags & JD_IMG_FUSED)) return;
+    const uint32_t lw = blockIdx.x - a.prefix[img];
+    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t s = lw * JD_F_LANES + threadIdx.x;
+    bool redo = false;
+    if (s >= 1u && s < nsub) redo = a.sub[im.subseq_base + s].entry != a.sub[im.subseq_base + s - 1u].exit;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(redo);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == first) {
+        base = atomicAdd(a.fcount + (uint32_t)round * (uint32_t)a.n_images + (uint32_t)img, (uint32_t)__popcll(m));
+        if (round >= JD_F_ROUNDS) atomicOr(&a.changed[32], 1u);
+    }
+    base = (uint32_t)__shfl((int)base, (int)first, 64);
+    if (redo) a.wl[im.subseq_base + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
+}
+
+__global__ __launch_bounds__(1024) void k1f_scan(JdKernelArgs a) {
+    __shared__ uint32_t tmp[16];
+    const int img = blockIdx.x;
+    const JdImg& im = a.imgs[img];
+    if (!(im.flags & JD_IMG_FUSED)) return;
+    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    for (uint32_t s0 = 0; s0 < nsub; s0 += 1024u) {
+        const uint32_t s = s0 + threadIdx.x;
+        uint32_t n = 0, d0 = 0, d1 = 0, d2 = 0;
+        if (s < nsub) { const JdSub r = a.sub[im.subseq_base + s]; n = r.nstart; d0 = (uint32_t)r.dc[0]; d1 = (uint32_t)r.dc[1]; d2 = (uint32_t)r.dc[2]; }
+        uint32_t t0, t1, t2, t3;
+        const uint32_t e0 = block_excl_scan(n, tmp, t0), e1 = block_excl_scan(d0, tmp, t1);
+        const uint32_t e2 = block_excl_scan(d1, tmp, t2), e3 = block_excl_scan(d2, tmp, t3);
+        if (s < nsub) {
+            JdSubPfx pf; pf.blk_off = r0 + e0; pf.dcp[0] = (int)(r1 + e1); pf.dcp[1] = (int)(r2 + e2); pf.dcp[2] = (int)(r3 + e3);
+            a.subpfx[im.subseq_base + s] = pf;
+        }
+        r0 += t0; r1 += t1; r2 += t2; r3 += t3;
+    }
+    // fewer blocks than the frame has = data ended early; surplus (bits after the last MCU) is ignored, as the reference
+    // stops reading once every MCU is decoded (main.go:769-770)
+    const uint32_t total = im.n_mcus * im.bpm;
+    if (r0 < total) {
+        if (threadIdx.x == 0) atomicOr(&a.status[img], (uint32_t)JD_ST_TRUNC);
+        // the blocks that never came: K2 reads SOME slot for them (the picture is reported as damaged anyway)
+        for (uint32_t j = r0 + threadIdx.x; j < total; j += 1024u) a.loc[im.loc_off + j] = make_uint2(0u, 0u);
+    }
+}
+
+__global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
+    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
+    const JdImg& im = a.imgs[img];
+    if (!(im.flags & JD_IMG_FUSED)) return;
+    const uint32_t lw = blockIdx.x - a.prefix[img];
+    const uint32_t sbits = a.stream_len[img] * 8u;
+    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t s = lw * JD_F_LANES + threadIdx.x;
+    if (s >= nsub) return;
+    const JdSub r = a.sub[im.subseq_base + s];
+    const JdSubPfx pf = a.subpfx[im.subseq_base + s];
+    const uint32_t total = im.n_mcus * im.bpm, bpm = im.bpm, nl = im.hs * im.vs;
+    if (pf.blk_off >= total || r.nstart == 0u) return;
+    const uint32_t nb = r.nstart < total - pf.blk_off ? r.nstart : total - pf.blk_off;
+    uint32_t err = 0;
+    uint32_t c = (r.entry >> 16) & 0xFFu;
+    if (c >= bpm || pf.blk_off % bpm != c) { err |= JD_ST_SYNC; c = pf.blk_off % bpm; }
+    if (nb == r.nstart) err |= r.first & 0xFFu;                   // errors in blocks the frame has
+    else if ((r.first >> 16) < nb) err |= (r.first >> 8) & 0xFFu;
+    // a block the frame needs ran past the end of the data
+    const uint32_t end_s = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
+    if (nb == r.nstart && end_s + (r.exit & 0xFFFFu) > sbits) err |= JD_ST_TRUNC;
+    if (err) atomicOr(&a.status[img], err);
+    const uint32_t* ctab = a.chunk + (uint64_t)(im.subseq_base + s) * a.fkmax;
+    uint2* out = a.loc + im.loc_off + pf.blk_off;
+    uint32_t ch = 0;
+    for (uint32_t j = 0; j < nb; j++) {
+        if ((j & (JD_F_CHUNK - 1u)) == 0u) ch = ctab[j / JD_F_CHUNK];
+        const uint32_t comp = c < nl ? 0u : c - nl + 1u;
+        out[j] = make_uint2(ch * JD_F_CHUNK + (j & (JD_F_CHUNK - 1u)), (uint32_t)(comp == 0u ? pf.dcp[0] : comp == 1u ? pf.dcp[1] : pf.dcp[2]));
+        c = (c + 1u == bpm) ? 0u : c + 1u;
+    }
 }
 
 // ---- DC-prediction prefix scan as its own pass --------------------------------------------------------------
@@ -1818,7 +2057,9 @@ __device__ __forceinline__ void k2_rtz_off() { asm volatile("s_setreg_imm32_b32 
 // are specialised per block.
 // C8: the image's coefficients are in the byte form (write_segments8): 64 bytes per block in the low plane, the high
 // plane only for blocks that carry the wide mark.
-template <int HS, int VS, int NC, bool C8>
+// ST (with C8): the image went through the single-decode path -- block b of the frame lives in the staging slot loc[b].x and
+// its DC is relative to loc[b].y (jd_internal.h).
+template <int HS, int VS, int NC, bool C8, bool ST = false>
 __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im, int img, uint32_t tile, const JdIdctConst& K) {
     constexpr uint32_t NL = HS * VS, BPM = NL + NC - 1;
     constexpr int NP = C8 ? 4 : 8;                                 // 16-byte pieces per block
@@ -1829,7 +2070,8 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     const uint8_t* const cplane = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off);
     const uint4* __restrict__ cbase = reinterpret_cast<const uint4*>(cplane + (uint64_t)M * BPM * (NP * 16u));
     typedef __attribute__((address_space(1))) const jd_u32x4 g_cu4;
-    g_cu4* const hbase = (g_cu4*)(cplane + ((uint64_t)im.n_mcus * BPM + (uint64_t)M * BPM) * 64u);   // C8: this MCU in the high plane
+    g_cu4* const hbase = ST ? (g_cu4*)(cplane + (uint64_t)im.slot_cap * 64u)                         // ST: the high plane, by slot
+                            : (g_cu4*)(cplane + ((uint64_t)im.n_mcus * BPM + (uint64_t)M * BPM) * 64u);   // C8: this MCU in the high plane
     const uint32_t rs = im.row_stride, W = im.width, H = im.height;
     // a copy (stores through it must not force reloads of `im`), in the GLOBAL address space: a generic-pointer
     // store could alias LDS, so hipcc would drain the LDS-DMA queue (and every earlier store) before each one
@@ -1850,15 +2092,27 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t stage_base = lds_abs_base() + 8192u + lane * 24u;  // LDS byte address of this lane's parked row 0
     auto block_of = [&](uint32_t st) { return st < (uint32_t)(NC - 1) ? NL + st : st - (uint32_t)(NC - 1); };   // chroma first
-    auto fetch = [&](uint32_t st) {
-        const uint4* src = cbase + block_of(st) * (uint32_t)NP;
+    auto fetch_from = [&](const uint4* src) {
 #pragma unroll
         for (int i = 0; i < NP; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
                                              (__attribute__((address_space(3))) void*)(dyn_lds + i * 1024),
                                              16, 0, 0);
     };
-    fetch(0);
+    auto fetch = [&](uint32_t st) { fetch_from(cbase + block_of(st) * (uint32_t)NP); };
+    // ST: where the blocks are -- the entry of block st + 1 is read while block st is computed, so the only wait for an
+    // entry is the first one.  A slot number is clamped to the staging (a truncated stream leaves entries unwritten).
+    typedef uint32_t locv __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) const locv g_cloc;
+    g_cloc* const locp = ST ? (g_cloc*)(a.loc + im.loc_off + (uint64_t)M * BPM) : nullptr;
+    const uint32_t slot_max = ST ? im.slot_cap - 1u : 0u;
+    auto slot_src = [&](uint32_t slot) { return reinterpret_cast<const uint4*>(cplane + (uint64_t)(slot < slot_max ? slot : slot_max) * 64u); };
+    locv lc_cur = { 0u, 0u }, lc_nxt = { 0u, 0u };
+    if constexpr (ST) {
+        lc_cur = locp[block_of(0)];
+        if (BPM > 1u) lc_nxt = locp[block_of(1)];
+        fetch_from(slot_src(lc_cur.x));
+    } else fetch(0);
 
     // (grey: one block per lane.  Left as straight-line code hipcc needs more than 256 registers for it -- it fits the
     // six-block loop of 4:2:0 into 218 -- so the trip count is hidden from it)
@@ -1898,7 +2152,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
             wflag = (cw[15] >> 28) == 8u;
             anyw = __builtin_amdgcn_ballot_w64(wflag) != 0;    // wave-uniform, rare
             if (anyw && wflag) {
-                g_cu4* hp = hbase + b * 4u;
+                g_cu4* hp = hbase + (ST ? (lc_cur.x < slot_max ? lc_cur.x : slot_max) : b) * 4u;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const jd_u32x4 v = hp[i]; hw[i * 4] = v.x; hw[i * 4 + 1] = v.y; hw[i * 4 + 2] = v.z; hw[i * 4 + 3] = v.w; }
                 // "use" them here: hipcc then waits for these loads inside this rare branch.  Left pending they made it
@@ -1908,7 +2162,14 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                 asm volatile("" : "+v"(hw[8]), "+v"(hw[9]), "+v"(hw[10]), "+v"(hw[11]), "+v"(hw[12]), "+v"(hw[13]), "+v"(hw[14]), "+v"(hw[15]));
             }
         }
-        if (st + 1u < n_steps) fetch(st + 1u);
+        const int dc_base = ST ? (int)lc_cur.y : 0;
+        if constexpr (ST) {
+            if (st + 1u < n_steps) {
+                fetch_from(slot_src(lc_nxt.x));
+                lc_cur = lc_nxt;
+                if (st + 2u < n_steps) lc_nxt = locp[block_of(st + 2u)];
+            }
+        } else if (st + 1u < n_steps) fetch(st + 1u);
         // column pass; its outputs are truncated to int as the reference does (main.go:521-528).  (Keeping them in fp64
         // with trunc() would save the 64 conversions back, but 128 registers of intermediates spill: 162 VGPRs spilled.)
         int mid[64];
@@ -1917,14 +2178,19 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
             auto qv_of = [&](int n) { return (int)((qw[n >> 2] >> ((n & 3) * 8)) & 0xFFu); };
             auto lo8 = [&](int zi) { return (int)(int8_t)(cw[zi >> 2] >> ((zi & 3) * 8)); };
             const int low4 = (int)(cw[15] << 4) >> 28;                  // byte 63 [3:0], sign-extended
-            const int dc = (int)((low4 << 8) | (int)(cw[0] & 0xFFu));
+            int dc = (int)((low4 << 8) | (int)(cw[0] & 0xFFu));
+            if (anyw && wflag) dc = (int)(((int)(int8_t)(hw[0] & 0xFFu) << 8) | (int)(cw[0] & 0xFFu));
+            if constexpr (ST) {
+                dc += dc_base;                                          // the writer's DC is relative to its sub-sequence
+                if (__builtin_expect(dc != (int)(short)dc, 0)) atomicOr(&a.status[img], (uint32_t)JD_ST_COEF);   // as the writers do
+            }
             if (anyw) {
                 auto hi8 = [&](int zi) { return (int)(int8_t)(hw[zi >> 2] >> ((zi & 3) * 8)); };
 #pragma unroll
                 for (int n = 0; n < 64; n++) {
                     const int zi = kZZ.n2z[n];
                     int cv;
-                    if (zi == 0) cv = wflag ? (int)((hi8(0) << 8) | (int)(cw[0] & 0xFFu)) : dc;
+                    if (zi == 0) cv = dc;
                     else if (zi == 63) cv = wflag ? (int)((low4 << 8) | (int)(hw[15] >> 24)) : ((int)cw[15] >> 28);
                     else cv = (int)(short)(lo8(zi) + (hi8(zi) << 8));   // (the high part is modulo 256: 32767 = -1 + (-128 << 8))
                     mid[n] = __mul24(cv, qv_of(n));
@@ -2135,17 +2401,17 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
 // needs 216.  A launch covers the batch's whole tile grid; tiles of images in another mode leave at once, and the
 // launcher only starts the modes the batch holds (jd_batch: k2_modes).
 __device__ __forceinline__ uint32_t k2_mode_of(const JdImg& im) { return im.ncomp == 1 ? 0u : im.hs + 2u * im.vs - 2u; }
-template <int MODE, bool C8>
+template <int MODE, bool C8, bool ST = false>
 __global__ __launch_bounds__(64, 2) void k2_mcu_lanes(JdKernelArgs a, JdIdctConst K) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
-    if (k2_mode_of(im) != (uint32_t)MODE || ((im.flags & JD_IMG_COEF8) != 0) != C8) return;   // wave-uniform
+    if (k2_mode_of(im) != (uint32_t)MODE || ((im.flags & JD_IMG_COEF8) != 0) != C8 || ((im.flags & JD_IMG_FUSED) != 0) != ST) return;   // wave-uniform
     const uint32_t tile = blockIdx.x - a.prefix[img];
-    if constexpr (MODE == 0) k2m_body<1, 1, 1, C8>(a, im, img, tile, K);
-    else if constexpr (MODE == 1) k2m_body<1, 1, 3, C8>(a, im, img, tile, K);
-    else if constexpr (MODE == 2) k2m_body<2, 1, 3, C8>(a, im, img, tile, K);
-    else if constexpr (MODE == 3) k2m_body<1, 2, 3, C8>(a, im, img, tile, K);
-    else k2m_body<2, 2, 3, C8>(a, im, img, tile, K);
+    if constexpr (MODE == 0) k2m_body<1, 1, 1, C8, ST>(a, im, img, tile, K);
+    else if constexpr (MODE == 1) k2m_body<1, 1, 3, C8, ST>(a, im, img, tile, K);
+    else if constexpr (MODE == 2) k2m_body<2, 1, 3, C8, ST>(a, im, img, tile, K);
+    else if constexpr (MODE == 3) k2m_body<1, 2, 3, C8, ST>(a, im, img, tile, K);
+    else k2m_body<2, 2, 3, C8, ST>(a, im, img, tile, K);
 }
 
 // byte form -> int16, zig-zag order: what jd_batch_coefficients hands out (one lane per block)
@@ -2156,11 +2422,19 @@ __global__ __launch_bounds__(256) void k_coef8_expand(JdKernelArgs a, int img, i
     if (blk >= nblocks) return;
     const uint8_t* lo = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + (uint64_t)blk * 64u;
     const uint8_t* hi = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + ((uint64_t)nblocks + blk) * 64u;
+    int dc_base = 0;
+    if (im.flags & JD_IMG_FUSED) {                                // staged: the block's slot and DC base
+        const uint2 l = a.loc[im.loc_off + blk];
+        const uint32_t slot = l.x < im.slot_cap ? l.x : im.slot_cap - 1u;
+        lo = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + (uint64_t)slot * 64u;
+        hi = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + ((uint64_t)im.slot_cap + slot) * 64u;
+        dc_base = (int)l.y;
+    }
     int16_t* o = out + (uint64_t)blk * 64u;
     const uint32_t b63 = lo[63];
     const bool wide = (b63 >> 4) == 8u;
     const int low4 = (int)((int32_t)(b63 << 28) >> 28);
-    o[0] = (int16_t)(((wide ? (int)(int8_t)hi[0] : low4) << 8) | (int)lo[0]);
+    o[0] = (int16_t)((((wide ? (int)(int8_t)hi[0] : low4) << 8) | (int)lo[0]) + dc_base);
     for (int k = 1; k < 63; k++) o[k] = (int16_t)((int)(int8_t)lo[k] + (wide ? ((int)(int8_t)hi[k] << 8) : 0));
     o[63] = wide ? (int16_t)((low4 << 8) | (int)hi[63]) : (int16_t)((int)(int8_t)b63 >> 4);
 }
@@ -2253,7 +2527,7 @@ void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, ui
     if (fmts & 2u) hipLaunchKernelGGL(k1_write_subseq<true>, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb);
 }
 
-// modes: bit (2 * m + f): some image has sampling mode m and coefficient form f (0 = int16, 1 = bytes)
+// modes: bit (3 * m + f): some image has sampling mode m and coefficient form f (0 = int16, 1 = bytes, 2 = bytes in staging)
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K,
                             hipStream_t s) {
     JdKernelArgs x = a; x.prefix = d_prefix;
@@ -2262,10 +2536,40 @@ void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uin
     // the left block's pixel rows (8 x 1536 B) -- the others must not pay for that in occupancy
 #define JD_K2_LAUNCH(M) \
     { const uint32_t lds = 8192u + ((M) == 2 || (M) == 4 ? 8u * 1536u : 0u); \
-      if (modes & (1u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, false>), dim3(wgs), dim3(64), lds, s, x, K); \
-      if (modes & (2u << (2 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, true>), dim3(wgs), dim3(64), lds, s, x, K); }
+      if (modes & (1u << (3 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, false>), dim3(wgs), dim3(64), lds, s, x, K); \
+      if (modes & (2u << (3 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, true>), dim3(wgs), dim3(64), lds, s, x, K); \
+      if (modes & (4u << (3 * M))) hipLaunchKernelGGL((k2_mcu_lanes<M, true, true>), dim3(wgs), dim3(64), lds, s, x, K); }
     JD_K2_LAUNCH(0) JD_K2_LAUNCH(1) JD_K2_LAUNCH(2) JD_K2_LAUNCH(3) JD_K2_LAUNCH(4)
 #undef JD_K2_LAUNCH
+}
+
+// ---- single-decode path: d_prefix = workgroups of JD_F_LANES lanes per image -------------------------------------------
+void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    const uint32_t lb = (lut_bytes + 15u) & ~15u;
+    hipLaunchKernelGGL(k1f_cold, dim3(wgs), dim3(JD_SYNC_WG), JD_SY_LUT + lb, s, x);
+}
+// round < 0: every sub-sequence; round >= 0: the sub-sequences k1f_check listed for that round
+void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    const uint32_t lb = (lut_bytes + 127u) & ~127u;
+    const uint32_t lds = lb + JD_W_WAVES * JD_WAVE_LDS;
+    if (lds > 64u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1f_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k1f_write, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb, round);
+}
+void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    hipLaunchKernelGGL(k1f_check, dim3(wgs), dim3(64 * JD_W_WAVES), 0, s, x, round);
+}
+void jdk_launch_fscan_index(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, hipStream_t s) {
+    if (!wgs) return;
+    JdKernelArgs x = a; x.prefix = d_prefix;
+    hipLaunchKernelGGL(k1f_scan, dim3(a.n_images), dim3(1024), 0, s, x);
+    hipLaunchKernelGGL(k1f_index, dim3(wgs), dim3(64 * JD_W_WAVES), 0, s, x);
 }
 
 void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, int16_t* d_out, hipStream_t s) {

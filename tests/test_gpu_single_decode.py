@@ -1,0 +1,116 @@
+"""GPU: the single-decode path of streams without restart markers (JD_IMG_FUSED: k1f_cold / k1f_write / k1f_check /
+k1f_scan / k1f_index, K2 reading coefficients through the block index) against the oracle, and against the two-pass path
+it replaces (JD_NODRI_FUSED=0) -- which stays the fallback and must stay correct.
+
+Knobs (read when a batch is created): JD_NODRI_FUSED=0 switches the path off; JD_DEBUG_FUSED_ROUNDS=n enqueues n blind
+re-decode rounds instead of 3, so that jd_batch_wait's loop has work; JD_DEBUG_FUSED_CAP_PERCENT=p gives the staging p % of
+the frame's blocks, so that it overflows and the batch falls back to the two-pass path."""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+import jpeg_decoder_amd as jd
+import orclib
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def knobs(**kw):
+    old = {k: os.environ.get(k) for k in kw}
+    os.environ.update({k: str(v) for k, v in kw.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _check(data):
+    o = orclib.OracleImage(data)
+    assert np.array_equal(jd.decode_coefficients(data), o.scan_order_coef())
+    assert np.array_equal(jd.decode_jpeg(data), o.rgb)
+
+
+GEOMETRIES = [(64, 48, 2, 2, 3), (333, 129, 2, 1, 3), (1040, 520, 1, 2, 3), (640, 360, 1, 1, 3), (2048, 1024, 2, 2, 3),
+              (1920, 1080, 2, 2, 3), (801, 601, 1, 1, 1), (16, 16, 2, 2, 3), (8, 8, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("w,h,hs,vs,nc", GEOMETRIES)
+def test_both_paths_against_the_oracle(w, h, hs, vs, nc, fused):
+    with knobs(JD_NODRI_FUSED=fused):
+        for q, detail in ((85, 2), (50, 1), (92, 3)):
+            _check(jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=w + q, detail=detail).encode(0))
+
+
+@pytest.mark.parametrize("rounds", [0, 1])
+def test_host_loop_finishes_what_blind_rounds_left(rounds):
+    """no (or one) blind re-decode round: one sub-sequence in twelve starts from a wrong guess, the last check sees it and
+    jd_batch_wait decodes, checks and re-indexes until nothing moves"""
+    with knobs(JD_DEBUG_FUSED_ROUNDS=rounds):
+        for seed, (w, h) in enumerate([(2048, 1024), (1920, 1080), (640, 360)]):
+            _check(jd.SynthImage(w, h, 2, 2, 3, quality=90, seed=seed, detail=3).encode(0))
+
+
+def test_staging_overflow_falls_back_to_the_two_pass_path():
+    with knobs(JD_DEBUG_FUSED_CAP_PERCENT=40):
+        data = jd.SynthImage(1920, 1080, 2, 2, 3, quality=85, seed=5, detail=2).encode(0)
+        _check(data)
+        # ... and a batch that fell back stays usable: run it again with other data of the same frames
+        ims = [jd.SynthImage(640, 360, 2, 2, 3, quality=85, seed=s, detail=2) for s in (1, 2, 3)]
+        files = [im.encode(0) for im in ims]
+        parsed = [jd.parse(f) for f in files]
+        b = jd.Batch([p[0] for p in parsed], [int(1.5 * max(p[2] for p in parsed))] * 3, keep_coef=True)
+        for rnd in range(2):
+            order = [0, 1, 2] if rnd == 0 else [2, 0, 1]
+            for i, k in enumerate(order):
+                b.upload(i, files[k][parsed[k][1]:parsed[k][1] + parsed[k][2]])
+            b.run(); b.wait()
+            for i, k in enumerate(order):
+                o = orclib.OracleImage(files[k])
+                assert np.array_equal(b.coefficients(i), o.scan_order_coef()), (rnd, i)
+                assert np.array_equal(b.download(i), o.rgb), (rnd, i)
+        b.close()
+
+
+def test_many_small_images_and_reuse_of_a_batch():
+    """one workgroup per image, lists of a few sub-sequences; the second run reuses records, chunk tables and lists"""
+    ims = [jd.SynthImage(96 + 16 * (s % 5), 64 + 8 * (s % 7), 2, 2, 3, quality=60 + 3 * (s % 11), seed=s, detail=1 + s % 3) for s in range(40)]
+    files = [im.encode(0) for im in ims]
+    parsed = [jd.parse(f) for f in files]
+    b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
+    for rnd in range(2):
+        for i, (f, p) in enumerate(zip(files, parsed)):
+            b.upload(i, f[p[1]:p[1] + p[2]])
+        b.run(); b.wait()
+        for i, f in enumerate(files):
+            o = orclib.OracleImage(f)
+            assert np.array_equal(b.coefficients(i), o.scan_order_coef()), (rnd, i)
+            assert np.array_equal(b.download(i), o.rgb), (rnd, i)
+    b.close()
+
+
+def test_truncated_and_damaged_streams_report_as_the_two_pass_path_does():
+    im = jd.SynthImage(640, 360, 2, 2, 3, quality=85, seed=9, detail=2)
+    data = im.encode(0)
+    fr, off, ln = jd.parse(data)
+    cut = data[:off + ln // 2] + data[off + ln:]
+    flip = bytearray(data); flip[off + ln // 3] ^= 0x5A; flip = bytes(flip)
+    for bad in (cut, flip):
+        codes = []
+        for fused in (1, 0):
+            with knobs(JD_NODRI_FUSED=fused):
+                try:
+                    jd.decode_jpeg(bad)
+                    codes.append(0)
+                except jd.JpegHipError as e:
+                    codes.append(e.code)
+        assert codes[0] == codes[1], codes
+    with pytest.raises(jd.JpegHipError):
+        jd.decode_jpeg(cut)

@@ -52,7 +52,9 @@ def test_shared_tables_with_dri_and_in_a_mixed_batch():
                                    {"JD_SYNC_FIXUPS": "1", "JD_DEBUG_SYNC_NO_WARM": "1"}])
 def test_host_fixup_loop(knobs):
     """jd_batch_wait's 'more fix-ups needed' branch: the sync pass is left incomplete on purpose (several sync
-    workgroups per image, no blind fix-ups and / or no warm-up), the host loop must finish it and re-run the consumers."""
+    workgroups per image, no blind fix-ups and / or no warm-up), the host loop must finish it and re-run the consumers.
+    (The two-pass path: these images would otherwise take the single-decode path, tests/test_gpu_single_decode.py.)"""
+    knobs = dict(knobs, JD_NODRI_FUSED="0")
     old = {k: os.environ.get(k) for k in knobs}
     os.environ.update(knobs)
     try:

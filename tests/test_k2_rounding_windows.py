@@ -22,7 +22,7 @@ def test_only_conversions_inside_rtz_windows(tmp_path):
                     "-o", str(out), SRC], check=True, capture_output=True, timeout=600)
     text = out.read_text()
     kernels = [f for f in re.split(r"\n(?=_Z\w+:)", text) if f.startswith("_Z12k2_mcu_lanes")]
-    assert len(kernels) == 10                                         # one per sampling mode and coefficient form
+    assert len(kernels) == 15                                         # one per sampling mode and coefficient form (int16, bytes, bytes in staging)
     windows = 0
     for k in kernels:
         inside = False
