@@ -283,10 +283,10 @@ struct jd_batch {
     uint32_t *d_status = nullptr, *d_stream_len = nullptr, *d_interval = nullptr, *d_changed = nullptr;
     size_t clear_bytes = 0;                   // d_status .. d_changed + 64 words
     unsigned long long* d_k0 = nullptr; uint32_t* d_ticket = nullptr; JdSub* d_sub = nullptr; JdSubPfx* d_subpfx = nullptr; JdSubCk* d_subck = nullptr; uint4* d_sync_tot = nullptr;
-    uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr, *d_pre_f = nullptr;
+    uint32_t *d_pre_k0 = nullptr, *d_pre_iv = nullptr, *d_pre_sync = nullptr, *d_pre_wr = nullptr, *d_pre_tile = nullptr, *d_pre_f = nullptr, *d_pre_fr = nullptr;
     // single-decode path of the streams without restart markers (JD_IMG_FUSED, jd_internal.h)
-    uint2* d_loc = nullptr; uint32_t *d_chunk = nullptr, *d_guess = nullptr, *d_wl = nullptr, *d_falloc = nullptr, *d_fcount = nullptr;
-    uint32_t fkmax = 0, wg_f = 0;
+    uint2* d_loc = nullptr; uint32_t *d_chunk = nullptr, *d_guess = nullptr, *d_wl = nullptr, *d_falloc = nullptr, *d_fhalloc = nullptr, *d_fcount = nullptr;
+    uint32_t fkmax = 0, wg_f = 0, wg_fr = 0;
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
     int fused_rounds = JD_F_ROUNDS;            // JD_DEBUG_FUSED_ROUNDS (0 .. JD_F_ROUNDS): fewer blind rounds, so that a test can
                                                // drive jd_batch_wait's extra rounds
@@ -331,9 +331,12 @@ JdKernelArgs kernel_args(const jd_batch* b) {
     a.imgs = b->d_img; a.n_images = b->n; a.prefix = nullptr; a.stream = b->d_stream; a.coef = b->d_coef;
     a.lut = b->d_lut; a.status = b->d_status; a.stream_len = b->d_stream_len; a.interval_start = b->d_interval;
     a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.subpfx = b->d_subpfx; a.subck = b->d_subck; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
-    a.loc = b->d_loc; a.chunk = b->d_chunk; a.guess = b->d_guess; a.wl = b->d_wl; a.falloc = b->d_falloc; a.fcount = b->d_fcount; a.fkmax = b->fkmax;
+    a.loc = b->d_loc; a.chunk = b->d_chunk; a.guess = b->d_guess; a.wl = b->d_wl; a.falloc = b->d_falloc; a.fhalloc = b->d_fhalloc; a.fcount = b->d_fcount; a.fkmax = b->fkmax;
     return a;
 }
+
+// single-decode path: staging slots set aside for the sub-sequences' own runs (a quarter more than the blocks + 16 each)
+uint64_t fused_own_budget(uint64_t nb, uint64_t nsub_cap) { return nb + nb / 4 + 16 * nsub_cap; }
 
 // recompute the per-kernel workgroup prefixes from the current ECS lengths and push the descriptor block: host
 // mirror in pinned memory, one asynchronous copy on the stream the kernels will run on
@@ -347,9 +350,9 @@ int refresh(jd_batch* b, hipStream_t s) {
     // ... and a run still in flight on ANOTHER stream must not see its descriptors change under it
     if (b->ran && b->last_stream != s) HIPCHK(hipStreamSynchronize(b->last_stream));
     JdImg* himg = reinterpret_cast<JdImg*>(b->h_desc);
-    uint32_t* pre[6];
-    for (int k = 0; k < 6; k++) pre[k] = reinterpret_cast<uint32_t*>(b->h_desc + align_up((size_t)n * sizeof(JdImg), 256) + (size_t)k * b->pre_stride);
-    for (int k = 0; k < 6; k++) pre[k][0] = 0;
+    uint32_t* pre[7];
+    for (int k = 0; k < 7; k++) pre[k] = reinterpret_cast<uint32_t*>(b->h_desc + align_up((size_t)n * sizeof(JdImg), 256) + (size_t)k * b->pre_stride);
+    for (int k = 0; k < 7; k++) pre[k][0] = 0;
     b->k2_modes = 0;
     for (int i = 0; i < n; i++) {
         JdImg& im = b->img[i];
@@ -365,10 +368,21 @@ int refresh(jd_batch* b, hipStream_t s) {
         pre[2][i + 1] = pre[2][i] + nsw;
         pre[3][i + 1] = pre[3][i] + (nsw * JD_SYNC_WG + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
         pre[4][i + 1] = pre[4][i] + im.n_tiles;
-        pre[5][i + 1] = pre[5][i] + (fz ? std::min(im.n_fwg, (nsub + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES)) : 0);
+        const uint32_t fwg = fz ? std::min(im.n_fwg, (nsub + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES)) : 0;
+        pre[5][i + 1] = pre[5][i] + fwg;
+        pre[6][i + 1] = pre[6][i] + (fwg + JD_F_REDO_DIV - 1) / JD_F_REDO_DIV;
+        if (fz) {
+            // slots every sub-sequence owns: a quarter more than the average it will hold (the stuffed length bounds the
+            // number of sub-sequences from above); the overflow chunks start behind them
+            const uint64_t nb = (uint64_t)im.n_mcus * im.bpm, ns = std::max<uint32_t>(nsub, 1);
+            uint64_t ch0 = ((nb + nb / 4) / ns + 8 + 7) & ~(uint64_t)7;
+            { const int dbg = env_int("JD_DEBUG_FUSED_CH0", 0); if (dbg > 0) ch0 = (uint64_t)dbg; }
+            if (ch0 * ns > fused_own_budget(nb, im.n_subseq_cap)) ch0 = 8;   // (cannot happen: ns <= n_subseq_cap)
+            im.f_ch0 = (uint32_t)ch0; im.f_ov_base = (uint32_t)(ch0 * ns);
+        }
         himg[i] = im;
     }
-    b->wg_k0 = pre[0][n]; b->wg_iv = pre[1][n]; b->wg_sync = pre[2][n]; b->wg_wr = pre[3][n]; b->wg_tile = pre[4][n]; b->wg_f = pre[5][n];
+    b->wg_k0 = pre[0][n]; b->wg_iv = pre[1][n]; b->wg_sync = pre[2][n]; b->wg_wr = pre[3][n]; b->wg_tile = pre[4][n]; b->wg_f = pre[5][n]; b->wg_fr = pre[6][n];
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc, b->desc_bytes, hipMemcpyHostToDevice, s));
     if (b->ev_desc) HIPCHK(hipEventRecord(b->ev_desc, s));
     b->desc_in_flight = true; b->last_stream = s;
@@ -411,7 +425,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
             jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, s);
             for (int r = 0; r < b->fused_rounds; r++) {
                 jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, r, s);
-                jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, r, s);
+                jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, s);
             }
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
             jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, s);
@@ -581,17 +595,20 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
         im.n_subseq_cap = (uint32_t)(((uint64_t)ecs_cap[i] * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
         im.coef_off = coef;
         if (fz) {
-            // staging: every block + a part-filled chunk per sub-sequence + room for what wrong guesses decode (if that
-            // is ever not enough the batch falls back to the two-pass path, JD_ST_FOVF)
+            // staging: the sub-sequences' own runs + overflow chunks for as many blocks again, a part-filled one for every
+            // second sub-sequence (if that is ever not enough the batch falls back to the two-pass path, JD_ST_FOVF)
             const uint64_t nb = (uint64_t)im.n_mcus * im.bpm;
-            uint64_t cap = nb + (uint64_t)JD_F_CHUNK * im.n_subseq_cap + nb / 4 + 64 * JD_F_CHUNK;
+            uint64_t cap = fused_own_budget(nb, im.n_subseq_cap) + nb + (uint64_t)(JD_F_CHUNK / 2) * im.n_subseq_cap + 64 * JD_F_CHUNK;
             const int pct = env_int("JD_DEBUG_FUSED_CAP_PERCENT", 0);   // tests: staging of pct % of the blocks, to see the fallback
-            if (pct > 0) cap = std::max<uint64_t>(nb * (uint64_t)pct / 100, 4 * JD_F_CHUNK);
+            if (pct > 0) cap = fused_own_budget(nb, im.n_subseq_cap) + std::max<uint64_t>(nb * (uint64_t)pct / 100, 4 * JD_F_CHUNK);
             if (cap >= (1ull << 31)) { batch_release(b); return JD_E_TOO_LARGE; }
             im.slot_cap = (uint32_t)cap;
             im.loc_off = locn; locn += (size_t)nb;
             im.n_fwg = (im.n_subseq_cap + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
-            coef += (size_t)std::max(cap, nb) * 64;           // (never less than the two-pass layout needs: the fallback uses it)
+            im.hi_cap = (uint32_t)(nb / 8 + 256);
+            // (never less than the two-pass layout needs: the fallback uses the region)
+            const uint64_t bytes_f = JD_F_HIPOOL_OFF(cap) + (uint64_t)im.hi_cap * 64, bytes_c = nb * 128;
+            coef += (size_t)((std::max(bytes_f, bytes_c) + 255) & ~(uint64_t)255) / 2;
             // chunk-table entries a sub-sequence can need: its shortest possible block is the shortest DC code plus the
             // shortest AC code (an EOB, or whatever the table offers)
             uint32_t minbits = 32;
@@ -618,7 +635,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     // ---- descriptor block: JdImg[n], then five prefixes of n + 1 words; read-back words follow in the pinned mirror ----
     const size_t img_bytes = align_up((size_t)n_images * sizeof(JdImg), 256);
     b->pre_stride = align_up((size_t)(n_images + 1) * sizeof(uint32_t), 256);
-    b->desc_bytes = img_bytes + 6 * b->pre_stride;
+    b->desc_bytes = img_bytes + 7 * b->pre_stride;
     const size_t lut_bytes = lut.size() * sizeof(uint16_t);
     const size_t pinned_need = b->desc_bytes + align_up((size_t)n_images * 4, 256) + 256 + (dev ? align_up(lut_bytes, 256) : 0);
 
@@ -635,11 +652,11 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     // status words and the sync pass's "changed" flags sit in one block: one clear per run instead of two
     // (and the single-decode path's chunk counters and list lengths: cleared by the same memset)
     const size_t st_words = align_up((size_t)n_images * 4, 256) / 4, fw = b->fkmax ? st_words : 0;
-    b->clear_bytes = (st_words + 64 + fw * (2 + JD_F_ROUNDS)) * 4;
+    b->clear_bytes = (st_words + 64 + fw * (3 + JD_F_ROUNDS)) * 4;
     A(&b->d_status, b->clear_bytes);
     if (rc == JD_OK) {
         b->d_changed = b->d_status + st_words;
-        if (b->fkmax) { b->d_falloc = b->d_changed + 64; b->d_fcount = b->d_falloc + fw; }
+        if (b->fkmax) { b->d_falloc = b->d_changed + 64; b->d_fhalloc = b->d_falloc + fw; b->d_fcount = b->d_fhalloc + fw; }
     }
     if (b->fkmax) {
         A(&b->d_loc, std::max<size_t>(locn, 1) * sizeof(uint2));
@@ -657,8 +674,8 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     A(&b->d_sync_tot, (size_t)swb * sizeof(uint4));
     if (rc == JD_OK) {
         b->d_img = reinterpret_cast<JdImg*>(b->d_desc);
-        uint32_t** pre[6] = { &b->d_pre_k0, &b->d_pre_iv, &b->d_pre_sync, &b->d_pre_wr, &b->d_pre_tile, &b->d_pre_f };
-        for (int k = 0; k < 6; k++) *pre[k] = reinterpret_cast<uint32_t*>(b->d_desc + img_bytes + (size_t)k * b->pre_stride);
+        uint32_t** pre[7] = { &b->d_pre_k0, &b->d_pre_iv, &b->d_pre_sync, &b->d_pre_wr, &b->d_pre_tile, &b->d_pre_f, &b->d_pre_fr };
+        for (int k = 0; k < 7; k++) *pre[k] = reinterpret_cast<uint32_t*>(b->d_desc + img_bytes + (size_t)k * b->pre_stride);
     }
     if (rc == JD_OK) {
         if (dev) {
@@ -782,7 +799,7 @@ int wait_on(jd_batch* b) {
         // single-decode path: the last check left a list; decode it, check again, until a check finds nothing
         guard = 0;
         if (more_f) do {
-            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, JD_F_ROUNDS, s);
+            jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, JD_F_ROUNDS, s);
             HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
             HIPCHK(hipMemsetAsync(b->d_fcount + (size_t)JD_F_ROUNDS * b->n, 0, (size_t)b->n * sizeof(uint32_t), s));
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);

@@ -119,16 +119,21 @@ enum {
 // ---- single-decode path for streams without restart markers (k1f_*) --------------------------------------------------
 // The two-pass path decodes every bit 2.6 times (blind pass, counting pass, corrections, writing pass) because a block's
 // place in the coefficient array is a prefix sum over everything before it.  Here the WRITING decode runs first, on a
-// guessed entry state, into STAGING: slots of 64 bytes handed out in chunks of JD_F_CHUNK to the sub-sequence that asks
-// (one atomic per wave and 16 block steps), DC values relative to the sub-sequence's start.  Lanes whose guess turns out
-// wrong (one in twelve) decode again into their own chunks; a scan over the per-sub-sequence counts then gives every
+// guessed entry state, into STAGING (slots of 64 bytes), DC values relative to the sub-sequence's start.  Sub-sequence s
+// owns the slots [s * f_ch0, (s + 1) * f_ch0) -- f_ch0 is a quarter more than the image's average blocks per sub-sequence,
+// so consecutive sub-sequences lie next to each other and most need nothing else -- and takes overflow chunks of
+// JD_F_CHUNK slots from a counter when it holds more (one atomic per wave and chunk).  Lanes whose guess turns out
+// wrong (one in twelve) decode again into their own slots; a scan over the per-sub-sequence counts then gives every
 // block its index, and k1f_index writes, per block, where it lives and what to add to its DC (JdKernelArgs::loc) -- K2
 // reads coefficients through that.  Decodes per bit: 0.5 (blind) + 1 + 0.1.
 // Sub-sequence state here: the first block START at or after a sub-sequence's end, as [15:0] its bit offset past that
 // end, [23:16] its block-in-MCU index.
-#define JD_F_CHUNK 16u
+#define JD_F_CHUNK 32u
 #define JD_F_ROUNDS 3              // re-decode rounds enqueued blindly; jd_batch_wait adds more while the last check finds work
-#define JD_F_KMAX_LIMIT 260u       // chunk-table entries per sub-sequence never exceed (4096 / 1 + 63) / 16
+#define JD_F_KMAX_LIMIT 132u       // chunk-table entries per sub-sequence never exceed (4096 / 1 + 63) / JD_F_CHUNK
+#define JD_F_HIMAP_OFF(slot_cap) ((uint64_t)(slot_cap) * 64u)                                   // byte offsets in the image's region
+#define JD_F_HIPOOL_OFF(slot_cap) (JD_F_HIMAP_OFF(slot_cap) + ((((uint64_t)(slot_cap) * 4u) + 63u) & ~(uint64_t)63u))
+#define JD_F_REDO_DIV 8u           // the re-decode launches run an eighth of the workgroups (each walks its share of the list)
 #define JD_FSTATE(rel, c) (0x80000000u | ((rel) > 0xFFFFu ? 0xFFFFu : (rel)) | ((c) << 16))
 
 
@@ -159,7 +164,12 @@ struct JdImg {
     uint64_t stream_off;         // byte offset of this image's region in the unstuffed buffer
     uint64_t coef_off;           // int16 offset in the coefficient buffer
     uint64_t loc_off;            // JD_IMG_FUSED: first entry of this image's blocks in JdKernelArgs::loc
-    uint32_t slot_cap;           // JD_IMG_FUSED: staging slots of this image (low plane: slot_cap x 64 B, then the high plane)
+    uint32_t slot_cap;           // JD_IMG_FUSED: staging slots of this image.  Its coefficient region: slot_cap x 64 B (low plane),
+                                 // slot_cap x 4 B (per slot: where a WIDE block's high parts are), hi_cap x 64 B (those high parts,
+                                 // handed out one by one: wide blocks are rare)
+    uint32_t hi_cap;
+    uint32_t f_ch0, f_ov_base;   // JD_IMG_FUSED: slots every sub-sequence owns; first slot of the overflow chunks (set per run
+                                 // from the stream's length)
     uint32_t n_fwg;              // JD_IMG_FUSED: workgroups of 64 * JD_W_WAVES lanes that cover its sub-sequences (capacity)
     uint8_t q[3][64];            // quantisation table per component, natural order
 };
@@ -230,10 +240,11 @@ struct JdKernelArgs {
     uint32_t* changed;           // sync: set when a workgroup's exit state changed
     // single-decode path (JD_IMG_FUSED)
     uint2* loc;                  // per block: (staging slot, DC base of its component at its sub-sequence's start)
-    uint32_t* chunk;             // per sub-sequence: fkmax chunk numbers (chunk k holds its blocks 16 k .. 16 k + 15)
+    uint32_t* chunk;             // per sub-sequence: fkmax overflow-chunk numbers (chunk k holds its blocks f_ch0 + JD_F_CHUNK * k ...)
     uint32_t* guess;             // per sub-sequence: blind guess of its exit state
     uint32_t* wl;                // per image (at subseq_base): sub-sequences to decode again
     uint32_t* falloc;            // per image: chunks handed out
+    uint32_t* fhalloc;           // per image: high-part slots handed out
     uint32_t* fcount;            // [JD_F_ROUNDS + 1][n_images]: length of the re-decode list of each round
     uint32_t fkmax;
 };

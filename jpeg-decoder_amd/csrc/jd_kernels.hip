@@ -720,8 +720,9 @@ struct FusedSeg {
     bool valid;              // the lane has a sub-sequence
     uint32_t c0;             // block-in-MCU index of its first block
     uint32_t entry;          // the entry state it decodes from (recorded for the next check)
-    uint32_t old_chunks;     // chunks an earlier decode of the sub-sequence already owns
+    uint32_t old_chunks;     // overflow chunks an earlier decode of the sub-sequence already owns
     uint32_t gsub;           // index of its record and chunk row (subseq_base + s)
+    uint32_t slot0;          // first of the slots it owns (s * f_ch0)
 };
 template <bool NT, bool FUSED = false>
 __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
@@ -778,12 +779,18 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     const uint32_t nblocks = im.n_mcus * bpm;
     uint8_t* const lo_plane = reinterpret_cast<uint8_t*>(a.coef + im.coef_off);
     typedef __attribute__((address_space(1))) uint8_t g_u8;
-    g_u8* const hi_plane = (g_u8*)(lo_plane + (uint64_t)(FUSED ? im.slot_cap : nblocks) * 64u);
-    // FUSED: chunk of the current 16 block steps (this lane's, and those of the four lanes whose blocks it helps to flush),
-    // blocks decoded, step of the first error, "ran out of chunk-table entries"
-    uint32_t cur_chunk = 0, f_chunk[4] = { 0, 0, 0, 0 }, my_nblk = 0, err_st = 0xFFFFu, err_first = 0;
+    g_u8* const hi_plane = (g_u8*)(lo_plane + (FUSED ? JD_F_HIPOOL_OFF(im.slot_cap) : (uint64_t)nblocks * 64u));
+    // FUSED: first slot of the chunk the walk is in (this lane's, and those of the four lanes whose blocks it helps to
+    // flush), blocks decoded, step of the first error, "ran out of staging"; wave-uniform: steps into the chunk, its size,
+    // overflow chunks so far
+    uint32_t cur_base = FUSED ? fs->slot0 : 0u, f_base[4] = { 0, 0, 0, 0 }, my_nblk = 0, err_st = 0xFFFFu, err_first = 0;
     bool stopped = false;
+    uint32_t sc = 0, lim = FUSED ? __builtin_amdgcn_readfirstlane(im.f_ch0) : 0u, kq = 0;
     uint32_t* const ctab = FUSED ? a.chunk + (uint64_t)fs->gsub * a.fkmax : nullptr;
+    if constexpr (FUSED) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) f_base[q] = (uint32_t)__shfl((int)cur_base, (int)(q * 16u + (lane >> 2)), 64);
+    }
 
     // flush plan: a block leaves as 64 bytes written by 4 lanes (16 B each) of one store instruction; in pass q lanes
     // 4t' .. 4t'+3 move the block of lane t = 16q + (lane >> 2)
@@ -843,7 +850,7 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             la_st4(f_src + q * 1024u, make_uint4(0, 0, 0, 0));
             if (FUSED ? ((am >> (q * 16u + (lane >> 2))) & 1ull) != 0 : st < f_end[q]) {
                 jd_u32x4 t; t.x = h.x; t.y = h.y; t.z = h.z; t.w = h.w;
-                jd_u32x4* at = FUSED ? reinterpret_cast<jd_u32x4*>(lo_plane + ((uint64_t)f_chunk[q] * JD_F_CHUNK + (st & (JD_F_CHUNK - 1u))) * 64u + part * 16u)
+                jd_u32x4* at = FUSED ? reinterpret_cast<jd_u32x4*>(lo_plane + (uint64_t)(f_base[q] + sc) * 64u + part * 16u)
                                      : reinterpret_cast<jd_u32x4*>(wave_dst + f_off[q] + (uint64_t)st * 64u);
                 if (NT) __builtin_nontemporal_store(t, at); else *at = t;
             }
@@ -932,11 +939,10 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             act = fs->valid && !stopped && cur_pos() < sg.end_bit;        // a block that STARTS inside the sub-sequence is its own
             act_mask = __builtin_amdgcn_ballot_w64(act);
             if (act_mask == 0) break;
-            if ((st & (JD_F_CHUNK - 1u)) == 0u) {                         // (wave-uniform) the next 16 blocks need a chunk
-                const uint32_t k = st / JD_F_CHUNK;
-                if (act && k >= a.fkmax) { stopped = true; act = false; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
-                const bool have = k < fs->old_chunks;
-                uint32_t ch = (act && have) ? ctab[k] : 0u;
+            if (sc == lim) {                                              // (wave-uniform) the lanes still walking need an overflow chunk
+                if (act && kq >= a.fkmax) { stopped = true; act = false; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
+                const bool have = kq < fs->old_chunks;
+                uint32_t ch = (act && have) ? ctab[kq] : 0u;
                 const uint64_t need = __builtin_amdgcn_ballot_w64(act && !have);
                 if (need) {                                               // one atomic per wave
                     const uint32_t first = (uint32_t)__builtin_ctzll(need);
@@ -945,14 +951,15 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
                     base = (uint32_t)__shfl((int)base, (int)first, 64);
                     if (act && !have) {
                         ch = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                        if ((ch + 1u) * JD_F_CHUNK > im.slot_cap) { ch = 0; stopped = true; act = false; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
-                        else ctab[k] = ch;
+                        if ((uint64_t)im.f_ov_base + ((uint64_t)ch + 1u) * JD_F_CHUNK > im.slot_cap) { ch = 0; stopped = true; act = false; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
+                        else ctab[kq] = ch;
                     }
                 }
-                cur_chunk = ch;
+                cur_base = im.f_ov_base + ch * JD_F_CHUNK;
                 act_mask = __builtin_amdgcn_ballot_w64(act);
 #pragma unroll
-                for (uint32_t q = 0; q < 4; q++) f_chunk[q] = (uint32_t)__shfl((int)cur_chunk, (int)(q * 16u + (lane >> 2)), 64);
+                for (uint32_t q = 0; q < 4; q++) f_base[q] = (uint32_t)__shfl((int)cur_base, (int)(q * 16u + (lane >> 2)), 64);
+                sc = 0; lim = JD_F_CHUNK; kq++;
             }
             my_nblk += act ? 1u : 0u;
         }
@@ -1030,7 +1037,12 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             const bool wide = wcnt != 0 || wide_dc || (uint32_t)(b63 + 7) > 14u;
             uint32_t low4 = dchi;
             if (__builtin_expect(wide, 0)) {
-                const uint32_t wblk = FUSED ? cur_chunk * JD_F_CHUNK + (st & (JD_F_CHUNK - 1u)) : sg.blk0 + st;
+                uint32_t wblk = sg.blk0 + st;
+                if constexpr (FUSED) {                                    // a high-part slot of its own, noted under the block's slot
+                    wblk = atomicAdd(a.fhalloc + img, 1u);
+                    if (wblk >= im.hi_cap) { wblk = 0; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
+                    reinterpret_cast<uint32_t*>(lo_plane + JD_F_HIMAP_OFF(im.slot_cap))[cur_base + sc] = wblk;
+                }
                 if (wcnt <= 4u) low4 = wide_from_list(wblk, dcv, b63, wl0, wl1, wcnt);
                 else {
                     const uint32_t rp = (rpb0 - rot) >> 2;
@@ -1046,6 +1058,7 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         wave_lds_order();
         if (act) c = (c + 1u == bpm) ? 0u : c + 1u;
         if constexpr (FUSED) {
+            sc++;
             const uint32_t now = err | (bad ? (uint32_t)JD_ST_HUFF : 0u);
             if (now != 0u && err_st == 0xFFFFu) { err_st = st; err_first = now; }
         }
@@ -1061,7 +1074,7 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             // [31:16] (the blocks behind the frame's last are garbage decoded from padding: their errors are nobody's)
             r.first = ((err | (bad ? (uint32_t)JD_ST_HUFF : 0u)) & 0xFFu) | ((err_first & 0xFFu) << 8) | (err_st << 16);
             r.dc[0] = p0; r.dc[1] = p1; r.dc[2] = p2;
-            const uint32_t nch = (my_nblk + JD_F_CHUNK - 1u) / JD_F_CHUNK;
+            const uint32_t nch = my_nblk > im.f_ch0 ? (my_nblk - im.f_ch0 + JD_F_CHUNK - 1u) / JD_F_CHUNK : 0u;   // overflow chunks it owns
             r.pad = nch > fs->old_chunks ? nch : fs->old_chunks;
             a.sub[fs->gsub] = r;
         }
@@ -1551,36 +1564,44 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, 
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     if (!(im.flags & JD_IMG_FUSED)) return;
-    const uint32_t lw = blockIdx.x - a.prefix[img];
+    const uint32_t lw = blockIdx.x - a.prefix[img], nwg = a.prefix[img + 1] - a.prefix[img];
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
-    const uint32_t L = lw * JD_F_LANES + threadIdx.x;
     const uint32_t n_todo = round < 0 ? nsub : a.fcount[(uint32_t)round * (uint32_t)a.n_images + (uint32_t)img];
     if (lw * JD_F_LANES >= n_todo) return;                      // whole workgroup idle (uniform)
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
-    FusedSeg fs; fs.valid = L < n_todo; fs.c0 = 0; fs.entry = JD_FSTATE(0u, 0u); fs.old_chunks = 0; fs.gsub = im.subseq_base;
-    Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
-    if (fs.valid) {
-        uint32_t s = L;
-        if (round >= 0) {
-            s = a.wl[im.subseq_base + L];
-            fs.old_chunks = a.sub[im.subseq_base + s].pad;
-            fs.entry = a.sub[im.subseq_base + s - 1u].exit;     // (the list never holds sub-sequence 0)
-        } else if (s) fs.entry = a.guess[im.subseq_base + s - 1u];
-        fs.gsub = im.subseq_base + s;
-        const uint32_t c0 = (fs.entry >> 16) & 0xFFu;
-        fs.c0 = c0 < im.bpm ? c0 : 0u;
-        sg.end_bit = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
-        sg.start_bit = s * JD_SUBSEQ_BITS + (fs.entry & 0xFFFFu);
-        if (sg.start_bit > sbits) sg.start_bit = sbits;          // (a block cannot start past the data; the walk then has nothing to do)
+    // (a re-decode launch has fewer workgroups than the list may have tiles: each walks its share)
+#pragma unroll 1
+    for (uint32_t tile = lw; tile * JD_F_LANES < n_todo; tile += nwg) {
+        const uint32_t L = tile * JD_F_LANES + threadIdx.x;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * JD_F_LANES + (threadIdx.x & ~63u))) >= n_todo) continue;   // wave-uniform
+        FusedSeg fs; fs.valid = L < n_todo; fs.c0 = 0; fs.entry = JD_FSTATE(0u, 0u); fs.old_chunks = 0; fs.gsub = im.subseq_base; fs.slot0 = 0;
+        Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
+        if (fs.valid) {
+            uint32_t s = L;
+            if (round >= 0) {
+                s = a.wl[im.subseq_base + L];
+                fs.old_chunks = a.sub[im.subseq_base + s].pad;
+                fs.entry = a.sub[im.subseq_base + s - 1u].exit;     // (the list never holds sub-sequence 0)
+            } else if (s) fs.entry = a.guess[im.subseq_base + s - 1u];
+            fs.gsub = im.subseq_base + s;
+            fs.slot0 = s * im.f_ch0;
+            const uint32_t c0 = (fs.entry >> 16) & 0xFFu;
+            fs.c0 = c0 < im.bpm ? c0 : 0u;
+            sg.end_bit = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
+            sg.start_bit = s * JD_SUBSEQ_BITS + (fs.entry & 0xFFFFu);
+            if (sg.start_bit > sbits) sg.start_bit = sbits;          // (a block cannot start past the data; the walk then has nothing to do)
+        }
+        write_segments8<true, true>(a, im, img, lut_bytes, sg, slen, 0u, &fs);
     }
-    write_segments8<true, true>(a, im, img, lut_bytes, sg, slen, 0u, &fs);
 }
 
-// round = the list to fill (0 .. JD_F_ROUNDS; the last one is only counted: a.changed[32] tells the host that blind rounds
-// were not enough)
+// round = the list to fill (0 .. JD_F_ROUNDS; after the last one a.changed[32] tells the host that blind rounds were not
+// enough).  One atomic per workgroup: the lists of an image share one counter.
 __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_check(JdKernelArgs a, int round) {
+    __shared__ uint32_t wcount[JD_W_WAVES];
+    __shared__ uint32_t wg_base;
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
     if (!(im.flags & JD_IMG_FUSED)) return;
@@ -1591,15 +1612,19 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_check(JdKernelArgs a, int
     bool redo = false;
     if (s >= 1u && s < nsub) redo = a.sub[im.subseq_base + s].entry != a.sub[im.subseq_base + s - 1u].exit;
     const uint64_t m = __builtin_amdgcn_ballot_w64(redo);
-    if (m == 0) return;
-    const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane == first) {
-        base = atomicAdd(a.fcount + (uint32_t)round * (uint32_t)a.n_images + (uint32_t)img, (uint32_t)__popcll(m));
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (lane == 0) wcount[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < JD_W_WAVES; k++) { const uint32_t n = wcount[k]; before += k < wv ? n : 0u; total += n; }
+    if (total == 0) return;                                    // (uniform)
+    if (threadIdx.x == 0) {
+        wg_base = atomicAdd(a.fcount + (uint32_t)round * (uint32_t)a.n_images + (uint32_t)img, total);
         if (round >= JD_F_ROUNDS) atomicOr(&a.changed[32], 1u);
     }
-    base = (uint32_t)__shfl((int)base, (int)first, 64);
-    if (redo) a.wl[im.subseq_base + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
+    __syncthreads();
+    if (redo) a.wl[im.subseq_base + wg_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
 }
 
 __global__ __launch_bounds__(1024) void k1f_scan(JdKernelArgs a) {
@@ -1633,6 +1658,8 @@ __global__ __launch_bounds__(1024) void k1f_scan(JdKernelArgs a) {
     }
 }
 
+// One wave per 64 sub-sequences, which it takes one at a time: lane j writes the entry of the sub-sequence's block j (and
+// j + 64, ...), so a sub-sequence's entries leave as one contiguous store.
 __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
     const int img = find_image(a.prefix, a.n_images, blockIdx.x);
     const JdImg& im = a.imgs[img];
@@ -1640,30 +1667,45 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t sbits = a.stream_len[img] * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
-    const uint32_t s = lw * JD_F_LANES + threadIdx.x;
-    if (s >= nsub) return;
-    const JdSub r = a.sub[im.subseq_base + s];
-    const JdSubPfx pf = a.subpfx[im.subseq_base + s];
-    const uint32_t total = im.n_mcus * im.bpm, bpm = im.bpm, nl = im.hs * im.vs;
-    if (pf.blk_off >= total || r.nstart == 0u) return;
-    const uint32_t nb = r.nstart < total - pf.blk_off ? r.nstart : total - pf.blk_off;
-    uint32_t err = 0;
-    uint32_t c = (r.entry >> 16) & 0xFFu;
-    if (c >= bpm || pf.blk_off % bpm != c) { err |= JD_ST_SYNC; c = pf.blk_off % bpm; }
-    if (nb == r.nstart) err |= r.first & 0xFFu;                   // errors in blocks the frame has
-    else if ((r.first >> 16) < nb) err |= (r.first >> 8) & 0xFFu;
-    // a block the frame needs ran past the end of the data
-    const uint32_t end_s = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
-    if (nb == r.nstart && end_s + (r.exit & 0xFFFFu) > sbits) err |= JD_ST_TRUNC;
-    if (err) atomicOr(&a.status[img], err);
-    const uint32_t* ctab = a.chunk + (uint64_t)(im.subseq_base + s) * a.fkmax;
-    uint2* out = a.loc + im.loc_off + pf.blk_off;
-    uint32_t ch = 0;
-    for (uint32_t j = 0; j < nb; j++) {
-        if ((j & (JD_F_CHUNK - 1u)) == 0u) ch = ctab[j / JD_F_CHUNK];
-        const uint32_t comp = c < nl ? 0u : c - nl + 1u;
-        out[j] = make_uint2(ch * JD_F_CHUNK + (j & (JD_F_CHUNK - 1u)), (uint32_t)(comp == 0u ? pf.dcp[0] : comp == 1u ? pf.dcp[1] : pf.dcp[2]));
-        c = (c + 1u == bpm) ? 0u : c + 1u;
+    const uint32_t s = lw * JD_F_LANES + threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t total = im.n_mcus * im.bpm, bpm = im.bpm, nl = im.hs * im.vs, ch0 = im.f_ch0, ovb = im.f_ov_base;
+    uint32_t nb = 0, c = 0, blk0 = 0;
+    int d0 = 0, d1 = 0, d2 = 0;
+    if (s < nsub) {
+        const JdSub r = a.sub[im.subseq_base + s];
+        const JdSubPfx pf = a.subpfx[im.subseq_base + s];
+        if (pf.blk_off < total && r.nstart != 0u) {
+            nb = r.nstart < total - pf.blk_off ? r.nstart : total - pf.blk_off;
+            blk0 = pf.blk_off; d0 = pf.dcp[0]; d1 = pf.dcp[1]; d2 = pf.dcp[2];
+            uint32_t err = 0;
+            c = (r.entry >> 16) & 0xFFu;
+            if (c >= bpm || blk0 % bpm != c) { err |= JD_ST_SYNC; c = blk0 % bpm; }
+            if (nb == r.nstart) err |= r.first & 0xFFu;                   // errors in blocks the frame has
+            else if ((r.first >> 16) < nb) err |= (r.first >> 8) & 0xFFu;
+            // a block the frame needs ran past the end of the data
+            const uint32_t end_s = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
+            if (nb == r.nstart && end_s + (r.exit & 0xFFFFu) > sbits) err |= JD_ST_TRUNC;
+            if (err) atomicOr(&a.status[img], err);
+        }
+    }
+    uint64_t todo = __builtin_amdgcn_ballot_w64(nb != 0u);
+    while (todo) {                                                         // (wave-uniform)
+        const int i = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t nb_i = (uint32_t)__builtin_amdgcn_readlane((int)nb, i), c_i = (uint32_t)__builtin_amdgcn_readlane((int)c, i);
+        const uint32_t blk_i = (uint32_t)__builtin_amdgcn_readlane((int)blk0, i);
+        const int e0 = __builtin_amdgcn_readlane(d0, i), e1 = __builtin_amdgcn_readlane(d1, i), e2 = __builtin_amdgcn_readlane(d2, i);
+        const uint32_t s_i = __builtin_amdgcn_readfirstlane(s - lane) + (uint32_t)i;
+        const uint32_t* ctab = a.chunk + (uint64_t)(im.subseq_base + s_i) * a.fkmax;
+        uint2* out = a.loc + im.loc_off + blk_i;
+        for (uint32_t j = lane; j < nb_i; j += 64u) {
+            uint32_t slot;
+            if (j < ch0) slot = s_i * ch0 + j;
+            else { const uint32_t o = j - ch0; slot = ovb + ctab[o / JD_F_CHUNK] * JD_F_CHUNK + (o & (JD_F_CHUNK - 1u)); }
+            const uint32_t cb = (c_i + j) % bpm;
+            const uint32_t comp = cb < nl ? 0u : cb - nl + 1u;
+            out[j] = make_uint2(slot, (uint32_t)(comp == 0u ? e0 : comp == 1u ? e1 : e2));
+        }
     }
 }
 
@@ -2070,7 +2112,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
     const uint8_t* const cplane = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off);
     const uint4* __restrict__ cbase = reinterpret_cast<const uint4*>(cplane + (uint64_t)M * BPM * (NP * 16u));
     typedef __attribute__((address_space(1))) const jd_u32x4 g_cu4;
-    g_cu4* const hbase = ST ? (g_cu4*)(cplane + (uint64_t)im.slot_cap * 64u)                         // ST: the high plane, by slot
+    g_cu4* const hbase = ST ? (g_cu4*)(cplane + JD_F_HIPOOL_OFF(im.slot_cap))                        // ST: the high parts, by their own slots
                             : (g_cu4*)(cplane + ((uint64_t)im.n_mcus * BPM + (uint64_t)M * BPM) * 64u);   // C8: this MCU in the high plane
     const uint32_t rs = im.row_stride, W = im.width, H = im.height;
     // a copy (stores through it must not force reloads of `im`), in the GLOBAL address space: a generic-pointer
@@ -2100,19 +2142,46 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
                                              16, 0, 0);
     };
     auto fetch = [&](uint32_t st) { fetch_from(cbase + block_of(st) * (uint32_t)NP); };
-    // ST: where the blocks are -- the entry of block st + 1 is read while block st is computed, so the only wait for an
-    // entry is the first one.  A slot number is clamped to the staging (a truncated stream leaves entries unwritten).
+    // ST: where the blocks are -- the MCU's BPM entries (48 contiguous bytes per lane) are read once, up front, and picked
+    // by the wave-uniform step.  (Read one step ahead inside the loop they cost 10 % of the kernel: the loop-carried copy of
+    // a loaded value puts a vmcnt(0) at the loop's end.)  A slot number is clamped to the staging (a truncated stream
+    // leaves entries unwritten).
     typedef uint32_t locv __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) const locv g_cloc;
     g_cloc* const locp = ST ? (g_cloc*)(a.loc + im.loc_off + (uint64_t)M * BPM) : nullptr;
     const uint32_t slot_max = ST ? im.slot_cap - 1u : 0u;
     auto slot_src = [&](uint32_t slot) { return reinterpret_cast<const uint4*>(cplane + (uint64_t)(slot < slot_max ? slot : slot_max) * 64u); };
-    locv lc_cur = { 0u, 0u }, lc_nxt = { 0u, 0u };
+    locv lcs[ST ? BPM : 1u];
+    auto loc_of = [&](uint32_t blk) {                            // blk: wave-uniform
+        locv r = lcs[0];
+        if constexpr (ST) {
+#pragma unroll
+            for (uint32_t k = 1; k < BPM; k++) {
+                r = blk == k ? lcs[k] : r;
+                asm volatile("" : "+v"(r));                      // (a select chain, not a table in scratch memory: see sel3)
+            }
+        }
+        return r;
+    };
+    locv lc_cur = { 0u, 0u };
     if constexpr (ST) {
-        lc_cur = locp[block_of(0)];
-        if (BPM > 1u) lc_nxt = locp[block_of(1)];
+#pragma unroll
+        for (uint32_t k = 0; k < BPM; k++) lcs[k] = locp[k];
+        lc_cur = loc_of(block_of(0));
         fetch_from(slot_src(lc_cur.x));
-    } else fetch(0);
+    } else {
+        lcs[0] = lc_cur;
+#ifdef JD_K2_EXP_DEP
+        {   // experiment: one dependent global load in front of the first DMA
+            typedef __attribute__((address_space(1))) const uint32_t g_cw;
+            uint32_t dummy = *(g_cw*)(cplane + (uint64_t)M * BPM * 64u + 20u);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy) :: "memory");
+            fetch_from(cbase + block_of(0) * (uint32_t)NP + (dummy & 0u));
+        }
+#else
+        fetch(0);
+#endif
+    }
 
     // (grey: one block per lane.  Left as straight-line code hipcc needs more than 256 registers for it -- it fits the
     // six-block loop of 4:2:0 into 218 -- so the trip count is hidden from it)
@@ -2152,7 +2221,13 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
             wflag = (cw[15] >> 28) == 8u;
             anyw = __builtin_amdgcn_ballot_w64(wflag) != 0;    // wave-uniform, rare
             if (anyw && wflag) {
-                g_cu4* hp = hbase + (ST ? (lc_cur.x < slot_max ? lc_cur.x : slot_max) : b) * 4u;
+                uint32_t hslot = b;
+                if constexpr (ST) {
+                    typedef __attribute__((address_space(1))) const uint32_t g_cw;
+                    hslot = ((g_cw*)(cplane + JD_F_HIMAP_OFF(im.slot_cap)))[lc_cur.x < slot_max ? lc_cur.x : slot_max];
+                    hslot = hslot < im.hi_cap ? hslot : 0u;
+                }
+                g_cu4* hp = hbase + hslot * 4u;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const jd_u32x4 v = hp[i]; hw[i * 4] = v.x; hw[i * 4 + 1] = v.y; hw[i * 4 + 2] = v.z; hw[i * 4 + 3] = v.w; }
                 // "use" them here: hipcc then waits for these loads inside this rare branch.  Left pending they made it
@@ -2165,9 +2240,12 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
         const int dc_base = ST ? (int)lc_cur.y : 0;
         if constexpr (ST) {
             if (st + 1u < n_steps) {
-                fetch_from(slot_src(lc_nxt.x));
-                lc_cur = lc_nxt;
-                if (st + 2u < n_steps) lc_nxt = locp[block_of(st + 2u)];
+                lc_cur = loc_of((uint32_t)__builtin_amdgcn_readfirstlane((int)block_of(st + 1u)));
+#ifdef JD_K2_EXP_DENSE
+                fetch_from(cbase + block_of(st + 1u) * (uint32_t)NP + (lc_cur.x & 0u));   // timing experiment: dense addresses
+#else
+                fetch_from(slot_src(lc_cur.x));
+#endif
             }
         } else if (st + 1u < n_steps) fetch(st + 1u);
         // column pass; its outputs are truncated to int as the reference does (main.go:521-528).  (Keeping them in fp64
@@ -2427,7 +2505,9 @@ __global__ __launch_bounds__(256) void k_coef8_expand(JdKernelArgs a, int img, i
         const uint2 l = a.loc[im.loc_off + blk];
         const uint32_t slot = l.x < im.slot_cap ? l.x : im.slot_cap - 1u;
         lo = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + (uint64_t)slot * 64u;
-        hi = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off) + ((uint64_t)im.slot_cap + slot) * 64u;
+        const uint8_t* base = reinterpret_cast<const uint8_t*>(a.coef + im.coef_off);
+        const uint32_t hs = (lo[63] >> 4) == 8u ? reinterpret_cast<const uint32_t*>(base + JD_F_HIMAP_OFF(im.slot_cap))[slot] : 0u;
+        hi = base + JD_F_HIPOOL_OFF(im.slot_cap) + (uint64_t)(hs < im.hi_cap ? hs : 0u) * 64u;
         dc_base = (int)l.y;
     }
     int16_t* o = out + (uint64_t)blk * 64u;
