@@ -617,7 +617,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                 for (uint32_t l = 16; l >= 1; l--) { if (f.huff[0][f.comp[c].td].bits[l - 1]) ld = l; if (f.huff[1][f.comp[c].ta].bits[l - 1]) la = l; }
                 minbits = std::min(minbits, ld + la);
             }
-            const uint32_t kmax = (JD_SUBSEQ_BITS / minbits + 1 + JD_F_CHUNK - 1) / JD_F_CHUNK + 1;
+            const uint32_t kmax = (JD_SUBSEQ_BITS / minbits + 1 + JD_F_CHUNK - 3) / (JD_F_CHUNK - 2) + 1;
             b->fkmax = std::max(b->fkmax, std::min<uint32_t>(kmax, JD_F_KMAX_LIMIT));
         } else coef += (size_t)im.n_mcus * im.bpm * 64;
         k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);

@@ -129,10 +129,13 @@ enum {
 // Sub-sequence state here: the first block START at or after a sub-sequence's end, as [15:0] its bit offset past that
 // end, [23:16] its block-in-MCU index.
 #define JD_F_CHUNK 32u
-#define JD_F_ROUNDS 3              // re-decode rounds enqueued blindly; jd_batch_wait adds more while the last check finds work
-#define JD_F_KMAX_LIMIT 132u       // chunk-table entries per sub-sequence never exceed (4096 / 1 + 63) / JD_F_CHUNK
+#define JD_F_ROUNDS 6              // re-decode rounds enqueued blindly; jd_batch_wait adds more while the last check finds work
+#define JD_F_KMAX_LIMIT 140u       // chunk-table entries per sub-sequence never exceed (4096 / 1 + 63) / (JD_F_CHUNK - 2)
 #define JD_F_HIMAP_OFF(slot_cap) ((uint64_t)(slot_cap) * 64u)                                   // byte offsets in the image's region
 #define JD_F_HIPOOL_OFF(slot_cap) (JD_F_HIMAP_OFF(slot_cap) + ((((uint64_t)(slot_cap) * 4u) + 63u) & ~(uint64_t)63u))
+#ifndef JD_F_CUT_DIV
+#define JD_F_CUT_DIV 16u           // first decode: a wave stops when no more than 1/16 of its lanes are still walking
+#endif
 #define JD_F_REDO_DIV 8u           // the re-decode launches run an eighth of the workgroups (each walks its share of the list)
 #define JD_FSTATE(rel, c) (0x80000000u | ((rel) > 0xFFFFu ? 0xFFFFu : (rel)) | ((c) << 16))
 

@@ -723,6 +723,10 @@ struct FusedSeg {
     uint32_t old_chunks;     // overflow chunks an earlier decode of the sub-sequence already owns
     uint32_t gsub;           // index of its record and chunk row (subseq_base + s)
     uint32_t slot0;          // first of the slots it owns (s * f_ch0)
+    bool cutoff;             // (wave-uniform) first decode: a wave does not wait for its last few lanes -- they are most likely
+                             // the ones that started from a wrong guess and walk through garbage; their record says "decode
+                             // me again" and the next round takes them (a decode from a checked entry state is never cut)
+    uint32_t guess_exit;     // ... and what the record of a lane that was cut hands its successor: the blind guess it used anyway
 };
 template <bool NT, bool FUSED = false>
 __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdImg& im, int img, uint32_t lut_bytes,
@@ -784,8 +788,14 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
     // flush), blocks decoded, step of the first error, "ran out of staging"; wave-uniform: steps into the chunk, its size,
     // overflow chunks so far
     uint32_t cur_base = FUSED ? fs->slot0 : 0u, f_base[4] = { 0, 0, 0, 0 }, my_nblk = 0, err_st = 0xFFFFu, err_first = 0;
-    bool stopped = false;
-    uint32_t sc = 0, lim = FUSED ? __builtin_amdgcn_readfirstlane(im.f_ch0) : 0u, kq = 0;
+    bool stopped = false, cut = false;
+    uint32_t n_first = 0;
+    // A lane whose first block is an odd one of its MCU starts at the second slot of every run (a run holds two blocks less
+    // than it has slots): blocks 2k and 2k + 1 of an MCU then share a 128-byte line, as in the dense layout -- K2 reads them
+    // in consecutive steps and the second read finds the line in L2 (a pair split over two lines is read five steps apart).
+    uint32_t sc = 0, lim = FUSED ? __builtin_amdgcn_readfirstlane(im.f_ch0) - 2u : 0u, kq = 0;
+    const uint32_t par = FUSED ? (fs->c0 & 1u) : 0u;
+    if constexpr (FUSED) cur_base += par;
     uint32_t* const ctab = FUSED ? a.chunk + (uint64_t)fs->gsub * a.fkmax : nullptr;
     if constexpr (FUSED) {
 #pragma unroll
@@ -939,6 +949,8 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
             act = fs->valid && !stopped && cur_pos() < sg.end_bit;        // a block that STARTS inside the sub-sequence is its own
             act_mask = __builtin_amdgcn_ballot_w64(act);
             if (act_mask == 0) break;
+            if (st == 0) n_first = (uint32_t)__popcll(act_mask);
+            if (fs->cutoff && n_first >= 32u && st >= 8u && (uint32_t)__popcll(act_mask) * JD_F_CUT_DIV <= n_first) { cut = act; break; }
             if (sc == lim) {                                              // (wave-uniform) the lanes still walking need an overflow chunk
                 if (act && kq >= a.fkmax) { stopped = true; act = false; atomicOr(&a.status[img], (uint32_t)JD_ST_FOVF); }
                 const bool have = kq < fs->old_chunks;
@@ -955,11 +967,11 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
                         else ctab[kq] = ch;
                     }
                 }
-                cur_base = im.f_ov_base + ch * JD_F_CHUNK;
+                cur_base = im.f_ov_base + ch * JD_F_CHUNK + par;
                 act_mask = __builtin_amdgcn_ballot_w64(act);
 #pragma unroll
                 for (uint32_t q = 0; q < 4; q++) f_base[q] = (uint32_t)__shfl((int)cur_base, (int)(q * 16u + (lane >> 2)), 64);
-                sc = 0; lim = JD_F_CHUNK; kq++;
+                sc = 0; lim = JD_F_CHUNK - 2u; kq++;
             }
             my_nblk += act ? 1u : 0u;
         }
@@ -1067,14 +1079,15 @@ __device__ __forceinline__ void write_segments8(const JdKernelArgs& a, const JdI
         if (fs->valid) {
             JdSub r;
             const uint32_t pos = cur_pos();
-            r.entry = fs->entry;
-            r.exit = JD_FSTATE(pos > sg.end_bit ? pos - sg.end_bit : 0u, c);
+            r.entry = cut ? 0u : fs->entry;                               // (0 is no state: the next check lists the lane)
+            r.exit = cut ? fs->guess_exit : JD_FSTATE(pos > sg.end_bit ? pos - sg.end_bit : 0u, c);
             r.nstart = my_nblk;
             // what went wrong: in all its blocks [7:0], in the first block that had an error [15:8], which block that was
             // [31:16] (the blocks behind the frame's last are garbage decoded from padding: their errors are nobody's)
             r.first = ((err | (bad ? (uint32_t)JD_ST_HUFF : 0u)) & 0xFFu) | ((err_first & 0xFFu) << 8) | (err_st << 16);
             r.dc[0] = p0; r.dc[1] = p1; r.dc[2] = p2;
-            const uint32_t nch = my_nblk > im.f_ch0 ? (my_nblk - im.f_ch0 + JD_F_CHUNK - 1u) / JD_F_CHUNK : 0u;   // overflow chunks it owns
+            const uint32_t own = im.f_ch0 - 2u;
+            const uint32_t nch = my_nblk > own ? (my_nblk - own + JD_F_CHUNK - 3u) / (JD_F_CHUNK - 2u) : 0u;   // overflow chunks it owns
             r.pad = nch > fs->old_chunks ? nch : fs->old_chunks;
             a.sub[fs->gsub] = r;
         }
@@ -1577,14 +1590,18 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, 
         const uint32_t L = tile * JD_F_LANES + threadIdx.x;
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * JD_F_LANES + (threadIdx.x & ~63u))) >= n_todo) continue;   // wave-uniform
         FusedSeg fs; fs.valid = L < n_todo; fs.c0 = 0; fs.entry = JD_FSTATE(0u, 0u); fs.old_chunks = 0; fs.gsub = im.subseq_base; fs.slot0 = 0;
+        fs.cutoff = round < 0; fs.guess_exit = 0;
         Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
         if (fs.valid) {
             uint32_t s = L;
             if (round >= 0) {
                 s = a.wl[im.subseq_base + L];
                 fs.old_chunks = a.sub[im.subseq_base + s].pad;
-                fs.entry = a.sub[im.subseq_base + s - 1u].exit;     // (the list never holds sub-sequence 0)
-            } else if (s) fs.entry = a.guess[im.subseq_base + s - 1u];
+                if (s) fs.entry = a.sub[im.subseq_base + s - 1u].exit;   // (sub-sequence 0 starts the stream: listed only if it was cut)
+            } else {
+                if (s) fs.entry = a.guess[im.subseq_base + s - 1u];
+                if (s + 1u < nsub) fs.guess_exit = a.guess[im.subseq_base + s];
+            }
             fs.gsub = im.subseq_base + s;
             fs.slot0 = s * im.f_ch0;
             const uint32_t c0 = (fs.entry >> 16) & 0xFFu;
@@ -1610,7 +1627,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_check(JdKernelArgs a, int
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     const uint32_t s = lw * JD_F_LANES + threadIdx.x;
     bool redo = false;
-    if (s >= 1u && s < nsub) redo = a.sub[im.subseq_base + s].entry != a.sub[im.subseq_base + s - 1u].exit;
+    if (s < nsub) redo = a.sub[im.subseq_base + s].entry != (s ? a.sub[im.subseq_base + s - 1u].exit : JD_FSTATE(0u, 0u));
     const uint64_t m = __builtin_amdgcn_ballot_w64(redo);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     if (lane == 0) wcount[wv] = (uint32_t)__popcll(m);
@@ -1669,7 +1686,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     const uint32_t s = lw * JD_F_LANES + threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t total = im.n_mcus * im.bpm, bpm = im.bpm, nl = im.hs * im.vs, ch0 = im.f_ch0, ovb = im.f_ov_base;
-    uint32_t nb = 0, c = 0, blk0 = 0;
+    uint32_t nb = 0, c = 0, blk0 = 0, par = 0;
     int d0 = 0, d1 = 0, d2 = 0;
     if (s < nsub) {
         const JdSub r = a.sub[im.subseq_base + s];
@@ -1679,6 +1696,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
             blk0 = pf.blk_off; d0 = pf.dcp[0]; d1 = pf.dcp[1]; d2 = pf.dcp[2];
             uint32_t err = 0;
             c = (r.entry >> 16) & 0xFFu;
+            par = (c < bpm ? c : 0u) & 1u;                                 // (what the writer placed its blocks by)
             if (c >= bpm || blk0 % bpm != c) { err |= JD_ST_SYNC; c = blk0 % bpm; }
             if (nb == r.nstart) err |= r.first & 0xFFu;                   // errors in blocks the frame has
             else if ((r.first >> 16) < nb) err |= (r.first >> 8) & 0xFFu;
@@ -1693,15 +1711,15 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
         const int i = (int)__builtin_ctzll(todo);
         todo &= todo - 1ull;
         const uint32_t nb_i = (uint32_t)__builtin_amdgcn_readlane((int)nb, i), c_i = (uint32_t)__builtin_amdgcn_readlane((int)c, i);
-        const uint32_t blk_i = (uint32_t)__builtin_amdgcn_readlane((int)blk0, i);
+        const uint32_t blk_i = (uint32_t)__builtin_amdgcn_readlane((int)blk0, i), par_i = (uint32_t)__builtin_amdgcn_readlane((int)par, i);
         const int e0 = __builtin_amdgcn_readlane(d0, i), e1 = __builtin_amdgcn_readlane(d1, i), e2 = __builtin_amdgcn_readlane(d2, i);
         const uint32_t s_i = __builtin_amdgcn_readfirstlane(s - lane) + (uint32_t)i;
         const uint32_t* ctab = a.chunk + (uint64_t)(im.subseq_base + s_i) * a.fkmax;
         uint2* out = a.loc + im.loc_off + blk_i;
         for (uint32_t j = lane; j < nb_i; j += 64u) {
             uint32_t slot;
-            if (j < ch0) slot = s_i * ch0 + j;
-            else { const uint32_t o = j - ch0; slot = ovb + ctab[o / JD_F_CHUNK] * JD_F_CHUNK + (o & (JD_F_CHUNK - 1u)); }
+            if (j < ch0 - 2u) slot = s_i * ch0 + par_i + j;
+            else { const uint32_t o = j - (ch0 - 2u), k = o / (JD_F_CHUNK - 2u); slot = ovb + ctab[k] * JD_F_CHUNK + par_i + (o - k * (JD_F_CHUNK - 2u)); }
             const uint32_t cb = (c_i + j) % bpm;
             const uint32_t comp = cb < nl ? 0u : cb - nl + 1u;
             out[j] = make_uint2(slot, (uint32_t)(comp == 0u ? e0 : comp == 1u ? e1 : e2));
