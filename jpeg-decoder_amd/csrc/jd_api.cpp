@@ -370,7 +370,7 @@ int refresh(jd_batch* b, hipStream_t s) {
         pre[4][i + 1] = pre[4][i] + im.n_tiles;
         const uint32_t fwg = fz ? std::min(im.n_fwg, (nsub + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES)) : 0;
         pre[5][i + 1] = pre[5][i] + fwg;
-        pre[6][i + 1] = pre[6][i] + (fwg + JD_F_REDO_DIV - 1) / JD_F_REDO_DIV;
+        pre[6][i + 1] = pre[6][i] + (fz ? (nsub + JD_F_REDO_LANES * JD_F_REDO_DIV - 1) / (JD_F_REDO_LANES * JD_F_REDO_DIV) : 0);
         if (fz) {
             // slots every sub-sequence owns: a quarter more than the average it will hold (the stuffed length bounds the
             // number of sub-sequences from above); the overflow chunks start behind them

@@ -136,7 +136,10 @@ enum {
 #ifndef JD_F_CUT_DIV
 #define JD_F_CUT_DIV 16u           // first decode: a wave stops when no more than 1/16 of its lanes are still walking
 #endif
-#define JD_F_REDO_DIV 8u           // the re-decode launches run an eighth of the workgroups (each walks its share of the list)
+#ifndef JD_F_REDO_LANES
+#define JD_F_REDO_LANES 256u       // lanes per workgroup of the re-decode launches
+#endif
+#define JD_F_REDO_DIV 8u           // ... which have an eighth of the lanes a full pass has (each workgroup walks its share of the list)
 #define JD_FSTATE(rel, c) (0x80000000u | ((rel) > 0xFFFFu ? 0xFFFFu : (rel)) | ((c) << 16))
 
 

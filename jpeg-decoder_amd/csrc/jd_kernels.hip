@@ -1578,17 +1578,19 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, 
     const JdImg& im = a.imgs[img];
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t lw = blockIdx.x - a.prefix[img], nwg = a.prefix[img + 1] - a.prefix[img];
+    const uint32_t wg_lanes = blockDim.x;                       // 64 * JD_W_WAVES for the first decode, JD_F_REDO_LANES for the lists
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     const uint32_t n_todo = round < 0 ? nsub : a.fcount[(uint32_t)round * (uint32_t)a.n_images + (uint32_t)img];
-    if (lw * JD_F_LANES >= n_todo) return;                      // whole workgroup idle (uniform)
+    if (lw * wg_lanes >= n_todo) return;                      // whole workgroup idle (uniform)
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
-    // (a re-decode launch has fewer workgroups than the list may have tiles: each walks its share)
+    // (a re-decode launch has fewer workgroups than the list may have tiles: each walks its share.  Its workgroups are small:
+    // a list is short, and a big workgroup with one busy wave would still hold its whole share of the CU's LDS)
 #pragma unroll 1
-    for (uint32_t tile = lw; tile * JD_F_LANES < n_todo; tile += nwg) {
-        const uint32_t L = tile * JD_F_LANES + threadIdx.x;
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * JD_F_LANES + (threadIdx.x & ~63u))) >= n_todo) continue;   // wave-uniform
+    for (uint32_t tile = lw; tile * wg_lanes < n_todo; tile += nwg) {
+        const uint32_t L = tile * wg_lanes + threadIdx.x;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * wg_lanes + (threadIdx.x & ~63u))) >= n_todo) continue;   // wave-uniform
         FusedSeg fs; fs.valid = L < n_todo; fs.c0 = 0; fs.entry = JD_FSTATE(0u, 0u); fs.old_chunks = 0; fs.gsub = im.subseq_base; fs.slot0 = 0;
         fs.cutoff = round < 0; fs.guess_exit = 0;
         Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
@@ -2653,10 +2655,10 @@ void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
-    const uint32_t lds = lb + JD_W_WAVES * JD_WAVE_LDS;
-    if (lds > 64u * 1024u)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1f_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k1f_write, dim3(wgs), dim3(64 * JD_W_WAVES), lds, s, x, lb, round);
+    const uint32_t lds = lb + (round < 0 ? JD_W_WAVES : JD_F_REDO_LANES / 64u) * JD_WAVE_LDS;
+    if (lb + JD_W_WAVES * JD_WAVE_LDS > 64u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1f_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb + JD_W_WAVES * JD_WAVE_LDS));
+    hipLaunchKernelGGL(k1f_write, dim3(wgs), dim3(round < 0 ? 64 * JD_W_WAVES : JD_F_REDO_LANES), lds, s, x, lb, round);
 }
 void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s) {
     if (!wgs) return;
