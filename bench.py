@@ -66,6 +66,13 @@ MODE_LABEL = {"resident": "(i) inputs and outputs resident in HBM",
               "host": "(iii) as (ii) + header parsing and ECS staging from whole files"}
 STAGE_KERNEL = {"unstuff": "k0_unstuff", "huffman_intervals": "k1_write_intervals", "huffman_sync": "k1_sync",
                 "huffman_write": "k1_write_subseq", "idct_colour": "k2_mcu_lanes"}
+# streams without restart markers take the single-decode path unless JD_NODRI_FUSED=0 (jd_internal.h): its stages
+STAGE_KERNEL_FUSED = dict(STAGE_KERNEL, huffman_sync="k1f_cold", huffman_write="k1f_write (+ k1f_check, k1f_scan, k1f_index)")
+
+
+def stage_kernel(stage, ri):
+    fused = ri == 0 and os.environ.get("JD_NODRI_FUSED", "1") != "0"
+    return (STAGE_KERNEL_FUSED if fused else STAGE_KERNEL).get(stage, stage)
 DTYPE = "f64 IDCT / f32 colour / int16 coefficients (bytes between the kernels)"
 TARGET_TIMED_S = 1.2     # what `--repeat 0` aims the timed region at
 
@@ -212,8 +219,8 @@ def cpu_baseline(jd, w, h, quality, detail, first):
     return _CPU_BASE[(w, h)]
 
 
-def recorded_traffic(wl, n_mine, kernel):
-    """HBM bytes per pass moved by `kernel` (all its launches) from the committed PMC passes (newest
+def recorded_traffic(wl, n_mine, stage):
+    """HBM bytes per pass moved by the kernels of `stage` (all their launches) from the committed PMC passes (newest
     profiles/rNN_traffic.json), if they were taken on this workload and batch.  PMC counters cannot be read from inside
     this process: the figure is RECORDED, not live (`traffic_source`)."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True):
@@ -221,7 +228,7 @@ def recorded_traffic(wl, n_mine, kernel):
             rec = json.load(open(path))["workloads"][wl]
             if rec["images_per_step"] != n_mine:
                 continue
-            return rec["kernels"][kernel]["hbm_bytes_per_step"], os.path.relpath(path, ROOT)
+            return rec["stages"][stage]["hbm_bytes_per_step"], os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -424,8 +431,8 @@ def run_resident(jd, R, wl, shard, args, headline):
         dom = max((k for k in stages if k != "clear"), key=lambda k: stages[k])
         alg_bytes = ecs_bytes + 3 * w * rows_mine               # stuffed ECS in + RGB8 out, per pass (this rank)
         achieved = alg_bytes / (stages[dom] * 1e-6) / 1e9
-        traffic, tsrc = recorded_traffic(wl, n_mine, STAGE_KERNEL.get(dom, dom)) if shard != "bands" else (None, None)
-        out["roofline"] = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "achieved": round(achieved, 1),
+        traffic, tsrc = recorded_traffic(wl, n_mine, dom) if shard != "bands" else (None, None)
+        out["roofline"] = {"bound": "hbm", "kernel": stage_kernel(dom, ri), "stage": dom, "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_source": ("recorded: " + tsrc) if tsrc else None,
                            "launch_us": round(stages[dom], 1), "algorithmic_bytes_per_launch": alg_bytes,

@@ -251,6 +251,9 @@ struct Arena {
     uint8_t* base = nullptr; size_t cap = 0, used = 0;
     std::vector<void*> owned;
     size_t total = 0;
+    int poison = -1;                          // JD_DEBUG_POISON=byte: every block starts filled with it (tests: nothing may depend
+                                              // on what freshly allocated device memory happens to hold)
+    int poison_only = -1, count = 0;          // JD_DEBUG_POISON_ONLY=k: ... only the k-th block taken
     bool fixed() const { return base != nullptr; }
     int take(void** p, size_t bytes) {
         bytes = std::max<size_t>(align_up(bytes, 256), 256);
@@ -261,6 +264,8 @@ struct Arena {
             HIPCHK(hipMalloc(p, bytes));
             owned.push_back(*p);
         }
+        if (poison >= 0 && (poison_only < 0 || poison_only == count)) HIPCHK(hipMemset(*p, poison, bytes));
+        count++;
         total += bytes;
         return JD_OK;
     }
@@ -376,7 +381,7 @@ int refresh(jd_batch* b, hipStream_t s) {
             // number of sub-sequences from above); the overflow chunks start behind them
             const uint64_t nb = (uint64_t)im.n_mcus * im.bpm, ns = std::max<uint32_t>(nsub, 1);
             uint64_t ch0 = ((nb + nb / 4) / ns + 8 + 7) & ~(uint64_t)7;
-            { const int dbg = env_int("JD_DEBUG_FUSED_CH0", 0); if (dbg > 0) ch0 = (uint64_t)dbg; }
+            { const int dbg = env_int("JD_DEBUG_FUSED_CH0", 0); if (dbg > 0) ch0 = std::max<uint64_t>((uint64_t)dbg & ~(uint64_t)1, 4); }   // tests: small runs, many overflow chunks
             if (ch0 * ns > fused_own_budget(nb, im.n_subseq_cap)) ch0 = 8;   // (cannot happen: ns <= n_subseq_cap)
             im.f_ch0 = (uint32_t)ch0; im.f_ov_base = (uint32_t)(ch0 * ns);
         }
@@ -482,6 +487,9 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     b->coef_form = env_int("JD_COEF_FORM", 0);                    // 8 / 16: force the coefficient form (tests); else per image
     if (b->coef_form != 8 && b->coef_form != 16) b->coef_form = 0;
     if (dev) { b->arena.base = dev->scratch; b->arena.cap = dev->scratch_bytes; }
+    b->arena.poison = env_int("JD_DEBUG_POISON", -1);
+    if (b->arena.poison > 255) b->arena.poison = -1;
+    b->arena.poison_only = env_int("JD_DEBUG_POISON_ONLY", -1);
     // the single-decode path needs staging beyond the fixed block of jd_decode_resident: batches of their own only
     b->fused = !dev && env_int("JD_NODRI_FUSED", 1) != 0;
     b->fused_rounds = std::min(std::max(env_int("JD_DEBUG_FUSED_ROUNDS", JD_F_ROUNDS), 0), JD_F_ROUNDS);
@@ -775,16 +783,18 @@ int wait_on(jd_batch* b) {
     b->desc_in_flight = false;
     // The single-decode path ran out of staging (speculative decodes of a hostile stream): the batch goes through the
     // two-pass path, from the top, and stays there.
-    if (b->wg_f) {
+    auto staging_overflowed = [&]() {
         bool ovf = false;
         for (int i = 0; i < b->n; i++) ovf = ovf || (b->h_status[i] & JD_ST_FOVF) != 0;
-        if (ovf) {
-            b->fused = false; b->dirty = true;
-            int rc = run_on(b, s); if (rc) return rc;
-            if (b->io_pending) { rc = enqueue_rgb_download(b); if (rc) return rc; }
-            return wait_on(b);
-        }
-    }
+        return ovf;
+    };
+    auto two_pass_from_the_top = [&]() -> int {
+        b->fused = false; b->dirty = true;
+        int rc = run_on(b, s); if (rc) return rc;
+        if (b->io_pending) { rc = enqueue_rgb_download(b); if (rc) return rc; }
+        return wait_on(b);
+    };
+    if (b->wg_f && staging_overflowed()) return two_pass_from_the_top();
     const bool more = b->wg_sync && (b->sync_fixups == 0 || b->h_changed[b->sync_fixups]);
     const bool more_f = b->wg_f && b->h_changed[32];
     if (more || more_f) {
@@ -804,7 +814,9 @@ int wait_on(jd_batch* b) {
             HIPCHK(hipMemsetAsync(b->d_fcount + (size_t)JD_F_ROUNDS * b->n, 0, (size_t)b->n * sizeof(uint32_t), s));
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
             HIPCHK(hipMemcpyAsync(b->h_changed, b->d_changed, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(b->h_status, b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (staging_overflowed()) return two_pass_from_the_top();   // (these rounds take staging too)
         } while (b->h_changed[32] && ++guard < 100000);
         // status bits and everything downstream of the sync records are recomputed
         HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->n * sizeof(uint32_t), s));

@@ -1418,14 +1418,19 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1_sync(JdKernelArgs a, int fix
         const uint32_t wv = threadIdx.x >> 6;
         const uint32_t pos = (wv > 0 ? n0 : 0u) + (wv > 1 ? n1 : 0u) + (wv > 2 ? n2 : 0u) +
                              (uint32_t)__popcll(bm & ((1ull << (threadIdx.x & 63u)) - 1ull));
-        uint32_t s_x = s, e_x = ne; bool run_x = changed, own_x = owned;
+        // ck_x: the sub-sequence HAS checkpoints of this run (JdSub::pad).  Not every first full decode is a MODE 1 one:
+        // sub-sequence 1 sits behind sub-sequence 0, which has no blind decode, so its entry state only changes in round 1
+        // (and with JD_DEBUG_SYNC_NO_WARM every workgroup's first lane waits for a fix-up launch).  A MODE 2 decode that
+        // trusted the checkpoint memory there compared its state with whatever an earlier batch had left in it -- and once
+        // in a few thousand images found a match (tests/test_gpu_sync.py::test_stale_checkpoints_are_not_trusted).
+        uint32_t s_x = s, e_x = ne; bool run_x = changed, own_x = owned, ck_x = owned && rec.pad != 0u;
         if (gather) {
-            if (changed) { re_src[pos] = s | (owned ? 0x80000000u : 0u); re_ent[pos] = ne; }
+            if (changed) { re_src[pos] = s | (owned ? 0x80000000u : 0u) | (ck_x ? 0x40000000u : 0u); re_ent[pos] = ne; }
             __syncthreads();
             run_x = threadIdx.x < n;
             s_x = run_x ? re_src[threadIdx.x] : 0u;
             e_x = run_x ? re_ent[threadIdx.x] : 0u;
-            own_x = (s_x >> 31) != 0; s_x &= 0x7FFFFFFFu;
+            own_x = (s_x >> 31) != 0; ck_x = ((s_x >> 30) & 1u) != 0; s_x &= 0x3FFFFFFFu;
         }
         JdSub r2 = rec;
         JdSubCk* const ckp = a.subck + im.subseq_base + s_x;
@@ -1433,8 +1438,9 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1_sync(JdKernelArgs a, int fix
             // the first round of the first launch is every sub-sequence's first full decode: it leaves the checkpoints
             // that every later decode (later rounds, gathered or not, and the fix-up launches) stops at
             if (!fixup && it == 0) spec_decode<1>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2, ckp, own_x);
-            else spec_decode<2>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2, ckp, own_x);
+            else spec_decode<2>(ik, Q, qmax, a.lut + im.lut_off, s_x, e_x, sbits, run_x, r2, ckp, ck_x);
         }
+        const bool recorded = !fixup && it == 0 && changed && owned;   // (this lane's sub-sequence got its checkpoints just now)
         if (gather) {
             if (run_x) {
                 re_out[threadIdx.x][0] = r2.exit; re_out[threadIdx.x][1] = r2.nstart; re_out[threadIdx.x][2] = r2.first;
@@ -1446,6 +1452,7 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1_sync(JdKernelArgs a, int fix
                 rec.dc[0] = (int)re_out[pos][3]; rec.dc[1] = (int)re_out[pos][4]; rec.dc[2] = (int)re_out[pos][5];
             }
         } else if (changed) rec = r2;
+        if (recorded) rec.pad = 1u;
     }
     if (owned) gsub[s] = rec;
     // workgroup totals for the spine scan

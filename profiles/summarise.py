@@ -72,6 +72,14 @@ for wl in ("c3", "c4", "c5"):
         "kernels": {k: {"FETCH_SIZE_KiB_per_launch": round(f[k]), "WRITE_SIZE_KiB_per_launch": round(w.get(k, 0)),
                         "launches_per_step": per_step[k],
                         "hbm_bytes_per_step": int((2 * f[k] + w.get(k, 0)) * 1024 * per_step[k])} for k in sorted(f)}}
+    # ... and per stage of jd_batch_run (what bench.py's stage times are): the kernels each stage launches
+    stages = {"unstuff": ["k0_unstuff"], "huffman_intervals": ["k1_write_intervals"],
+              "huffman_sync": ["k1_sync", "k1_sync_spine", "k1f_cold"],
+              "huffman_write": ["k1_write_subseq", "k1_dc_scan", "k1f_write", "k1f_check", "k1f_scan", "k1f_index"],
+              "idct_colour": ["k2_mcu_lanes"]}
+    kk = traffic["workloads"][wl]["kernels"]
+    traffic["workloads"][wl]["stages"] = {s: {"kernels": [k for k in ks if k in kk], "hbm_bytes_per_step": sum(kk[k]["hbm_bytes_per_step"] for k in ks if k in kk)}
+                                          for s, ks in stages.items() if any(k in kk for k in ks)}
     traffic["workloads"][wl]["hbm_bytes_per_step_all_kernels"] = sum(v["hbm_bytes_per_step"] for v in traffic["workloads"][wl]["kernels"].values())
     cs = {}
     for part in ("sq1_", "sq2_"):

@@ -14,21 +14,58 @@ while time.time() - t0 < budget:
     mcus = ((w + 8 * hs - 1) // (8 * hs)) * ((h + 8 * vs - 1) // (8 * vs))
     ri = rng.choice([0, 0, 1, 2, 3, 7, 8, 16, max(1, mcus // 3), mcus + 5])
     if ri > 65535: ri = 0
+    if os.environ.get("FUZZ_CLASSIC"):                # the two-pass path alone
+        ri = 0; os.environ["JD_NODRI_FUSED"] = "0"
+    elif os.environ.get("FUZZ_NODRI"):                  # stress the single-decode path: no restart markers, random knobs
+        ri = 0
+        for k, vals in (("JD_DEBUG_FUSED_ROUNDS", [None, None, 0, 1, 2]), ("JD_DEBUG_FUSED_CH0", [None, None, 4, 8, 24]),
+                        ("JD_DEBUG_FUSED_CAP_PERCENT", [None, None, None, 30]), ("JD_NODRI_FUSED", [None, None, None, None, 0])):
+            v = rng.choice(vals)
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = str(v)
     form = rng.choice([None, 8, 16])
     flags = rng.choice([0, 0, 0, jd.SynthImage.SHARED_TABLES])
-    im = jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=rng.randrange(1 << 30), detail=detail)
+    seed = rng.randrange(1 << 30)
+    im = jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=seed, detail=detail)
     data, twin = im.encode(ri, flags), im.encode(0, flags)
+    lo_hi = os.environ.get("FUZZ_WINDOW")              # "a:b": draw every case, run only cases a .. b - 1 (a quick way back to a failure)
+    if lo_hi:
+        a_, b_ = (int(x) for x in lo_hi.split(":"))
+        if n >= b_: break
+        if n < a_:
+            n += 1; continue
+        print("case", n, (w, h, hs, vs, nc, q, detail, ri, form, flags, seed), flush=True)
     if form is None: os.environ.pop("JD_COEF_FORM", None)
     else: os.environ["JD_COEF_FORM"] = str(form)
     try:
         c = jd.decode_coefficients(data); rgb = jd.decode_jpeg(data)
         o = orclib.OracleImage(twin)
-        ok = np.array_equal(c, im.coefficients()) and np.array_equal(rgb, o.rgb)
+        okc, okp = np.array_equal(c, im.coefficients()), np.array_equal(rgb, o.rgb)
+        ok = okc and okp
+        if not ok: print("coef ok", okc, "pixels ok", okp)
     except Exception as e:
         ok = False; print("EXC", e)
     n += 1
     if time.time() - t_say > 30:                      # (a silent GPU command is taken to be hung)
         t_say = time.time(); print("...", n, "cases,", bad, "bad", flush=True)
     if not ok:
-        bad += 1; print("MISMATCH", w, h, hs, vs, nc, q, detail, ri, form, flags)
+        again = []
+        for _ in range(3):                            # does it fail again?  (a fault that comes and goes is a race or stale memory)
+            try:
+                again.append(bool(np.array_equal(jd.decode_coefficients(data), im.coefficients())) and bool(np.array_equal(jd.decode_jpeg(data), o.rgb)))
+            except Exception as e:
+                again.append(str(e)[-40:])
+        print("again:", again)
+        for knob in ({"JD_DEBUG_POISON": "0"}, {"JD_DEBUG_POISON": "165"}, {"JD_SYNC_FIXUPS": "8"}, {"JD_COEF_FORM": "16"}, {"JD_NODRI_FUSED": "1"}, {}):
+            saved = {k: os.environ.get(k) for k in knob}
+            os.environ.update(knob)
+            try:
+                r = bool(np.array_equal(jd.decode_coefficients(data), im.coefficients()))
+            except Exception as e:
+                r = str(e)[-30:]
+            print("   with", knob, "->", r)
+            for k, v in saved.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        bad += 1; print("MISMATCH", w, h, hs, vs, nc, q, detail, ri, form, flags, "seed", seed, {k: v for k, v in os.environ.items() if k.startswith("JD_")}, flush=True)
 print("cases", n, "bad", bad)

@@ -71,3 +71,32 @@ def test_host_fixup_loop(knobs):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_stale_checkpoints_are_not_trusted():
+    """Round 3, found by tests/fuzz_parity.py (FUZZ_CLASSIC=1, case 1073 of seed 11): sub-sequence 1 of an image gets its
+    first full decode in round 1 of k1_sync -- a MODE 2 decode, which stops at the first checkpoint whose state it
+    reproduces -- but its checkpoints are only written by a MODE 1 decode.  It compared its state with whatever the
+    checkpoint memory held from an earlier batch, and after this big image and this small one the third image's state
+    matched a stale record: wrong block count, 'Error! EOF'.  Checkpoints are now trusted only when JdSub::pad says this run
+    wrote them.  (The sequence depends on the allocator handing the third decode the first one's memory: it did, every
+    time, in a fresh process and in the fuzz run.)"""
+    old = {k: os.environ.get(k) for k in ("JD_NODRI_FUSED", "JD_COEF_FORM")}
+    os.environ["JD_NODRI_FUSED"] = "0"
+    try:
+        for (w, h, hs, vs, q, detail, form, seed) in [(1920, 1500, 2, 1, 98, 3, None, 662586496), (8, 777, 1, 1, 100, 1, 8, 380998917),
+                                                      (1023, 200, 2, 1, 60, 1, 8, 786934824)]:
+            if form is None:
+                os.environ.pop("JD_COEF_FORM", None)
+            else:
+                os.environ["JD_COEF_FORM"] = str(form)
+            im = jd.SynthImage(w, h, hs, vs, 3, quality=q, seed=seed, detail=detail)
+            data = im.encode(0)
+            assert np.array_equal(jd.decode_coefficients(data), im.coefficients()), (w, h)
+            assert np.array_equal(jd.decode_jpeg(data), orclib.OracleImage(data).rgb), (w, h)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
