@@ -293,8 +293,10 @@ struct jd_batch {
     uint2* d_loc = nullptr; uint32_t *d_chunk = nullptr, *d_guess = nullptr, *d_wl = nullptr, *d_falloc = nullptr, *d_fhalloc = nullptr, *d_fcount = nullptr;
     uint32_t fkmax = 0, wg_f = 0, wg_fr = 0;
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
+    bool fused_always = false;                 // JD_NODRI_FUSED=2: whatever the batch's size (tests)
+    std::vector<uint8_t> fz_ok;                // per image: planned for the single-decode path (staging allocated)
     int fused_rounds = JD_F_ROUNDS;            // JD_DEBUG_FUSED_ROUNDS (0 .. JD_F_ROUNDS): fewer blind rounds, so that a test can
-                                               // drive jd_batch_wait's extra rounds
+    int fused_rounds_env = -1;                 // drive jd_batch_wait's extra rounds; unset: by the batch's size
     // pinned host mirror of the descriptor block, followed by the read-back words (status per image, 64 sync flags)
     uint8_t* h_desc = nullptr; size_t desc_bytes = 0, pre_stride = 0;
     uint32_t *h_status = nullptr, *h_changed = nullptr;
@@ -359,12 +361,27 @@ int refresh(jd_batch* b, hipStream_t s) {
     for (int k = 0; k < 7; k++) pre[k] = reinterpret_cast<uint32_t*>(b->h_desc + align_up((size_t)n * sizeof(JdImg), 256) + (size_t)k * b->pre_stride);
     for (int k = 0; k < 7; k++) pre[k][0] = 0;
     b->k2_modes = 0;
+    // Which no-DRI path this run takes.  The single-decode path is the THROUGHPUT path: it decodes every bit 1.6 times
+    // instead of 2.6, but its critical path is longer (blind decode, writing decode and two or three re-decode rounds are
+    // each one walk through a sub-sequence, ~200 us for a lone wave; the two-pass path has 2.5 such walks), so it only
+    // pays once the writing decode fills the machine several times over.  Measured cross-over (MI355X, q85 images,
+    // sub-sequences = stream bits / 4096): 1080p from ~200 images per batch (+17 % slower at 64 images = 77,000
+    // sub-sequences, +9 % at 128, -10 % at 256 = 307,000 and beyond), 8192 x 8192 from ~20 (+41 % for one image = 58,000,
+    // +1 % at 16 = 925,000, -6 % at 32, -11 % at 64): big images need more (their per-image steps -- prefix scan, lists --
+    // are serial), hence the two-part rule.
+    bool fz_now = b->fused;
+    if (fz_now && !b->fused_always) {
+        uint64_t subs = 0, nfz = 0;
+        for (int i = 0; i < n; i++)
+            if (b->fz_ok[i]) { subs += ((uint64_t)b->img[i].ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS; nfz++; }
+        fz_now = nfz && (subs >= 900000 || (subs >= 250000 && subs / nfz <= 4096));
+    }
     for (int i = 0; i < n; i++) {
         JdImg& im = b->img[i];
         const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
         im.n_k0_chunks = stuffed ? (uint32_t)((im.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK) : 0;
         const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
-        if (!b->fused) im.flags &= ~(uint32_t)JD_IMG_FUSED;
+        if (fz_now && b->fz_ok[i]) im.flags |= JD_IMG_FUSED; else im.flags &= ~(uint32_t)JD_IMG_FUSED;
         const bool fz = (im.flags & JD_IMG_FUSED) != 0;
         const uint32_t nsw = (im.restart_interval || fz) ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_OWN - 1) / JD_SYNC_OWN);
         b->k2_modes |= (fz ? 4u : (im.flags & JD_IMG_COEF8) ? 2u : 1u) << (3 * (im.ncomp == 1 ? 0 : im.hs + 2 * im.vs - 2));
@@ -388,6 +405,9 @@ int refresh(jd_batch* b, hipStream_t s) {
         himg[i] = im;
     }
     b->wg_k0 = pre[0][n]; b->wg_iv = pre[1][n]; b->wg_sync = pre[2][n]; b->wg_wr = pre[3][n]; b->wg_tile = pre[4][n]; b->wg_f = pre[5][n]; b->wg_fr = pre[6][n];
+    // blind re-decode rounds: what a round leaves shrinks by an order of magnitude, so a small batch needs fewer (each is
+    // two launches on the critical path; jd_batch_wait finishes what a last check still finds)
+    if (b->fused_rounds_env < 0) b->fused_rounds = (uint64_t)b->wg_f * 64 * JD_W_WAVES < 200000 ? 3 : JD_F_ROUNDS;
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc, b->desc_bytes, hipMemcpyHostToDevice, s));
     if (b->ev_desc) HIPCHK(hipEventRecord(b->ev_desc, s));
     b->desc_in_flight = true; b->last_stream = s;
@@ -492,7 +512,10 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
     b->arena.poison_only = env_int("JD_DEBUG_POISON_ONLY", -1);
     // the single-decode path needs staging beyond the fixed block of jd_decode_resident: batches of their own only
     b->fused = !dev && env_int("JD_NODRI_FUSED", 1) != 0;
-    b->fused_rounds = std::min(std::max(env_int("JD_DEBUG_FUSED_ROUNDS", JD_F_ROUNDS), 0), JD_F_ROUNDS);
+    b->fused_always = env_int("JD_NODRI_FUSED", 1) == 2;
+    b->fz_ok.assign(n_images, 0);
+    b->fused_rounds_env = env_int("JD_DEBUG_FUSED_ROUNDS", -1);
+    if (b->fused_rounds_env >= 0) b->fused_rounds = std::min(b->fused_rounds_env, JD_F_ROUNDS);
 
     // ---- Huffman table sets, de-duplicated across the batch -----------------------------------------
     std::vector<uint16_t> lut;
@@ -535,7 +558,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
         } else if (b->coef_form == 16) bytes = false;
         if (bytes) im.flags |= JD_IMG_COEF8;
         const bool fz = b->fused && bytes && f.restart_interval == 0;
-        if (fz) im.flags |= JD_IMG_FUSED;
+        if (fz) { im.flags |= JD_IMG_FUSED; b->fz_ok[i] = 1; }
         b->coef_fmts |= bytes ? 2u : 1u;
         b->k2_modes |= (fz ? 4u : bytes ? 2u : 1u) << (3 * (f.ncomp == 1 ? 0 : g.hs + 2 * g.vs - 2));
         const unsigned unit = bytes ? 1u : 2u;

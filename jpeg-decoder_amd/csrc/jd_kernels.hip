@@ -1653,30 +1653,61 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_check(JdKernelArgs a, int
     if (redo) a.wl[im.subseq_base + wg_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
 }
 
+// exclusive scan of four values at once over a thread block (<= 1024 threads; `tmp`: 16 uint4 of LDS)
+__device__ __forceinline__ uint4 block_excl_scan4(uint4 v, uint4* tmp, uint4& total) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint4 inc = make_uint4(wave_incl_scan(v.x), wave_incl_scan(v.y), wave_incl_scan(v.z), wave_incl_scan(v.w));
+    __syncthreads();
+    if (lane == 63) tmp[wv] = inc;
+    __syncthreads();
+    const int nw = (int)((blockDim.x + 63u) >> 6);
+    uint4 t = lane < nw ? tmp[lane] : make_uint4(0, 0, 0, 0);
+    t = make_uint4(row_incl_scan(t.x), row_incl_scan(t.y), row_incl_scan(t.z), row_incl_scan(t.w));
+    auto rl = [&](uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); };
+    total = make_uint4(rl(t.x, nw - 1), rl(t.y, nw - 1), rl(t.z, nw - 1), rl(t.w, nw - 1));
+    uint4 base = make_uint4(0, 0, 0, 0);
+    if (wv) base = make_uint4(rl(t.x, wv - 1), rl(t.y, wv - 1), rl(t.z, wv - 1), rl(t.w, wv - 1));
+    return make_uint4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
+}
+
+// One workgroup per image; a thread takes JD_F_SCAN_PER consecutive sub-sequences per trip, so an 8192 x 8192 image's
+// 58,000 sub-sequences are 8 trips (one sub-sequence per thread and four separate scans per trip made this kernel a
+// 130-us serial step of every batch, however small).
+#define JD_F_SCAN_PER 8u
 __global__ __launch_bounds__(1024) void k1f_scan(JdKernelArgs a) {
-    __shared__ uint32_t tmp[16];
+    __shared__ uint4 tmp[16];
     const int img = blockIdx.x;
     const JdImg& im = a.imgs[img];
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t sbits = a.stream_len[img] * 8u;
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
-    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    for (uint32_t s0 = 0; s0 < nsub; s0 += 1024u) {
-        const uint32_t s = s0 + threadIdx.x;
-        uint32_t n = 0, d0 = 0, d1 = 0, d2 = 0;
-        if (s < nsub) { const JdSub r = a.sub[im.subseq_base + s]; n = r.nstart; d0 = (uint32_t)r.dc[0]; d1 = (uint32_t)r.dc[1]; d2 = (uint32_t)r.dc[2]; }
-        uint32_t t0, t1, t2, t3;
-        const uint32_t e0 = block_excl_scan(n, tmp, t0), e1 = block_excl_scan(d0, tmp, t1);
-        const uint32_t e2 = block_excl_scan(d1, tmp, t2), e3 = block_excl_scan(d2, tmp, t3);
-        if (s < nsub) {
-            JdSubPfx pf; pf.blk_off = r0 + e0; pf.dcp[0] = (int)(r1 + e1); pf.dcp[1] = (int)(r2 + e2); pf.dcp[2] = (int)(r3 + e3);
-            a.subpfx[im.subseq_base + s] = pf;
+    uint4 run = make_uint4(0, 0, 0, 0);                          // (blocks, DC sums) before this trip
+    for (uint32_t s0 = 0; s0 < nsub; s0 += 1024u * JD_F_SCAN_PER) {
+        const uint32_t first = s0 + threadIdx.x * JD_F_SCAN_PER;
+        uint4 v[JD_F_SCAN_PER];
+        uint4 mine = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t e = 0; e < JD_F_SCAN_PER; e++) {
+            v[e] = make_uint4(0, 0, 0, 0);
+            if (first + e < nsub) { const JdSub r = a.sub[im.subseq_base + first + e]; v[e] = make_uint4(r.nstart, (uint32_t)r.dc[0], (uint32_t)r.dc[1], (uint32_t)r.dc[2]); }
+            mine.x += v[e].x; mine.y += v[e].y; mine.z += v[e].z; mine.w += v[e].w;
         }
-        r0 += t0; r1 += t1; r2 += t2; r3 += t3;
+        uint4 tot;
+        uint4 at = block_excl_scan4(mine, tmp, tot);
+        at.x += run.x; at.y += run.y; at.z += run.z; at.w += run.w;
+#pragma unroll
+        for (uint32_t e = 0; e < JD_F_SCAN_PER; e++) {
+            if (first + e < nsub) {
+                JdSubPfx pf; pf.blk_off = at.x; pf.dcp[0] = (int)at.y; pf.dcp[1] = (int)at.z; pf.dcp[2] = (int)at.w;
+                a.subpfx[im.subseq_base + first + e] = pf;
+            }
+            at.x += v[e].x; at.y += v[e].y; at.z += v[e].z; at.w += v[e].w;
+        }
+        run.x += tot.x; run.y += tot.y; run.z += tot.z; run.w += tot.w;
     }
     // fewer blocks than the frame has = data ended early; surplus (bits after the last MCU) is ignored, as the reference
     // stops reading once every MCU is decoded (main.go:769-770)
-    const uint32_t total = im.n_mcus * im.bpm;
+    const uint32_t r0 = run.x, total = im.n_mcus * im.bpm;
     if (r0 < total) {
         if (threadIdx.x == 0) atomicOr(&a.status[img], (uint32_t)JD_ST_TRUNC);
         // the blocks that never came: K2 reads SOME slot for them (the picture is reported as damaged anyway)
@@ -2198,16 +2229,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
         fetch_from(slot_src(lc_cur.x));
     } else {
         lcs[0] = lc_cur;
-#ifdef JD_K2_EXP_DEP
-        {   // experiment: one dependent global load in front of the first DMA
-            typedef __attribute__((address_space(1))) const uint32_t g_cw;
-            uint32_t dummy = *(g_cw*)(cplane + (uint64_t)M * BPM * 64u + 20u);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy) :: "memory");
-            fetch_from(cbase + block_of(0) * (uint32_t)NP + (dummy & 0u));
-        }
-#else
         fetch(0);
-#endif
     }
 
     // (grey: one block per lane.  Left as straight-line code hipcc needs more than 256 registers for it -- it fits the
@@ -2268,11 +2290,7 @@ __device__ __forceinline__ void k2m_body(const JdKernelArgs& a, const JdImg& im,
         if constexpr (ST) {
             if (st + 1u < n_steps) {
                 lc_cur = loc_of((uint32_t)__builtin_amdgcn_readfirstlane((int)block_of(st + 1u)));
-#ifdef JD_K2_EXP_DENSE
-                fetch_from(cbase + block_of(st + 1u) * (uint32_t)NP + (lc_cur.x & 0u));   // timing experiment: dense addresses
-#else
                 fetch_from(slot_src(lc_cur.x));
-#endif
             }
         } else if (st + 1u < n_steps) fetch(st + 1u);
         // column pass; its outputs are truncated to int as the reference does (main.go:521-528).  (Keeping them in fp64

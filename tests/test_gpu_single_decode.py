@@ -2,7 +2,9 @@
 k1f_scan / k1f_index, K2 reading coefficients through the block index) against the oracle, and against the two-pass path
 it replaces (JD_NODRI_FUSED=0) -- which stays the fallback and must stay correct.
 
-Knobs (read when a batch is created): JD_NODRI_FUSED=0 switches the path off; JD_DEBUG_FUSED_ROUNDS=n enqueues n blind
+The library picks the path per run by the batch's size (the single-decode path is the throughput path: jd_api.cpp,
+refresh()); the images here are small, so the tests force it.
+Knobs (read when a batch is created): JD_NODRI_FUSED=0 switches the path off, =2 takes it whatever the size; JD_DEBUG_FUSED_ROUNDS=n enqueues n blind
 re-decode rounds instead of 3, so that jd_batch_wait's loop has work; JD_DEBUG_FUSED_CAP_PERCENT=p gives the staging p % of
 the frame's blocks, so that it overflows and the batch falls back to the two-pass path."""
 import contextlib
@@ -41,7 +43,7 @@ GEOMETRIES = [(64, 48, 2, 2, 3), (333, 129, 2, 1, 3), (1040, 520, 1, 2, 3), (640
               (1920, 1080, 2, 2, 3), (801, 601, 1, 1, 1), (16, 16, 2, 2, 3), (8, 8, 1, 1, 1)]
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [2, 0])
 @pytest.mark.parametrize("w,h,hs,vs,nc", GEOMETRIES)
 def test_both_paths_against_the_oracle(w, h, hs, vs, nc, fused):
     with knobs(JD_NODRI_FUSED=fused):
@@ -53,13 +55,13 @@ def test_both_paths_against_the_oracle(w, h, hs, vs, nc, fused):
 def test_host_loop_finishes_what_blind_rounds_left(rounds):
     """no (or one) blind re-decode round: one sub-sequence in twelve starts from a wrong guess, the last check sees it and
     jd_batch_wait decodes, checks and re-indexes until nothing moves"""
-    with knobs(JD_DEBUG_FUSED_ROUNDS=rounds):
+    with knobs(JD_DEBUG_FUSED_ROUNDS=rounds, JD_NODRI_FUSED=2):
         for seed, (w, h) in enumerate([(2048, 1024), (1920, 1080), (640, 360)]):
             _check(jd.SynthImage(w, h, 2, 2, 3, quality=90, seed=seed, detail=3).encode(0))
 
 
 def test_staging_overflow_falls_back_to_the_two_pass_path():
-    with knobs(JD_DEBUG_FUSED_CAP_PERCENT=40):
+    with knobs(JD_DEBUG_FUSED_CAP_PERCENT=40, JD_NODRI_FUSED=2):
         data = jd.SynthImage(1920, 1080, 2, 2, 3, quality=85, seed=5, detail=2).encode(0)
         _check(data)
         # ... and a batch that fell back stays usable: run it again with other data of the same frames
@@ -84,7 +86,8 @@ def test_many_small_images_and_reuse_of_a_batch():
     ims = [jd.SynthImage(96 + 16 * (s % 5), 64 + 8 * (s % 7), 2, 2, 3, quality=60 + 3 * (s % 11), seed=s, detail=1 + s % 3) for s in range(40)]
     files = [im.encode(0) for im in ims]
     parsed = [jd.parse(f) for f in files]
-    b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
+    with knobs(JD_NODRI_FUSED=2):
+        b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
     for rnd in range(2):
         for i, (f, p) in enumerate(zip(files, parsed)):
             b.upload(i, f[p[1]:p[1] + p[2]])
@@ -96,6 +99,25 @@ def test_many_small_images_and_reuse_of_a_batch():
     b.close()
 
 
+def test_the_path_is_chosen_by_size_and_both_choices_are_right():
+    """default knobs: a batch of two images stays on the two-pass path, one with enough stream for the machine (96 images of
+    ~2970 sub-sequences: above the rule's 250,000) takes the single-decode path; either way the pictures are the oracle's"""
+    im = jd.SynthImage(1920, 1080, 2, 2, 3, quality=92, seed=77, detail=3)
+    data = im.encode(0)
+    fr, off, ln = jd.parse(data)
+    want = orclib.OracleImage(data)
+    for n in (2, 96):
+        assert n == 2 or n * ((ln * 8 + 4095) // 4096) >= 250000, ln
+        b = jd.Batch([fr] * n, [ln] * n, keep_coef=True)
+        for i in range(n):
+            b.upload(i, data[off:off + ln])
+        b.run(); b.wait()
+        for i in (0, n // 2, n - 1):
+            assert np.array_equal(b.coefficients(i), want.scan_order_coef()), (n, i)
+            assert np.array_equal(b.download(i), want.rgb), (n, i)
+        b.close()
+
+
 def test_truncated_and_damaged_streams_report_as_the_two_pass_path_does():
     im = jd.SynthImage(640, 360, 2, 2, 3, quality=85, seed=9, detail=2)
     data = im.encode(0)
@@ -104,7 +126,7 @@ def test_truncated_and_damaged_streams_report_as_the_two_pass_path_does():
     flip = bytearray(data); flip[off + ln // 3] ^= 0x5A; flip = bytes(flip)
     for bad in (cut, flip):
         codes = []
-        for fused in (1, 0):
+        for fused in (2, 0):
             with knobs(JD_NODRI_FUSED=fused):
                 try:
                     jd.decode_jpeg(bad)
