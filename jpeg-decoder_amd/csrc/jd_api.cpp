@@ -34,7 +34,7 @@ void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, i
 void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
 void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, hipStream_t s);
 void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s);
-void jdk_launch_fscan_index(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, hipStream_t s);
+void jdk_launch_fscan_index(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int tiled, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_idct_colour(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t modes, const JdIdctConst& K, hipStream_t s);
 void jdk_launch_pscan(const JdKernelArgs& a, const JdPScan* d_scans, const uint32_t* d_list, int n, const uint8_t* d_pstream,
@@ -292,6 +292,7 @@ struct jd_batch {
     // single-decode path of the streams without restart markers (JD_IMG_FUSED, jd_internal.h)
     uint2* d_loc = nullptr; uint32_t *d_chunk = nullptr, *d_guess = nullptr, *d_wl = nullptr, *d_falloc = nullptr, *d_fhalloc = nullptr, *d_fcount = nullptr;
     uint32_t fkmax = 0, wg_f = 0, wg_fr = 0;
+    int fscan_tiled = 0;                        // some image has more than 8192 sub-sequences: prefix scan in tiles
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
     bool fused_always = false;                 // JD_NODRI_FUSED=2: whatever the batch's size (tests)
     std::vector<uint8_t> fz_ok;                // per image: planned for the single-decode path (staging allocated)
@@ -360,7 +361,7 @@ int refresh(jd_batch* b, hipStream_t s) {
     uint32_t* pre[7];
     for (int k = 0; k < 7; k++) pre[k] = reinterpret_cast<uint32_t*>(b->h_desc + align_up((size_t)n * sizeof(JdImg), 256) + (size_t)k * b->pre_stride);
     for (int k = 0; k < 7; k++) pre[k][0] = 0;
-    b->k2_modes = 0;
+    b->k2_modes = 0; b->fscan_tiled = 0;
     // Which no-DRI path this run takes.  The single-decode path is the THROUGHPUT path: it decodes every bit 1.6 times
     // instead of 2.6, but its critical path is longer (blind decode, writing decode and two or three re-decode rounds are
     // each one walk through a sub-sequence, ~200 us for a lone wave; the two-pass path has 2.5 such walks), so it only
@@ -391,6 +392,7 @@ int refresh(jd_batch* b, hipStream_t s) {
         pre[3][i + 1] = pre[3][i] + (nsw * JD_SYNC_WG + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
         pre[4][i + 1] = pre[4][i] + im.n_tiles;
         const uint32_t fwg = fz ? std::min(im.n_fwg, (nsub + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES)) : 0;
+        if (fz && nsub > 8192) b->fscan_tiled = 1;
         pre[5][i + 1] = pre[5][i] + fwg;
         pre[6][i + 1] = pre[6][i] + (fz ? (nsub + JD_F_REDO_LANES * JD_F_REDO_DIV - 1) / (JD_F_REDO_LANES * JD_F_REDO_DIV) : 0);
         if (fz) {
@@ -453,7 +455,7 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
                 jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, s);
             }
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
-            jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, s);
+            jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, b->fscan_tiled, s);
         }
         break;
     case ST_IDCT_COLOUR:
@@ -850,7 +852,7 @@ int wait_on(jd_batch* b) {
             jdk_launch_write_subseq(a, b->d_pre_wr, b->wg_wr, b->max_w_bytes, b->coef_fmts, s);
             if (b->wg_wr && b->any_uniform) jdk_launch_dc_scan(a, s);
         }
-        jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, s);
+        jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, b->fscan_tiled, s);
         int rc = enqueue_stage(b, ST_IDCT_COLOUR, s); if (rc) return rc;
         if (b->io_pending) { rc = enqueue_rgb_download(b); if (rc) return rc; }
         HIPCHK(hipMemcpyAsync(b->h_status, b->d_status, (size_t)b->n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
