@@ -368,14 +368,15 @@ int refresh(jd_batch* b, hipStream_t s) {
     // pays once the writing decode fills the machine several times over.  Measured cross-over (MI355X, q85 images,
     // sub-sequences = stream bits / 4096): 1080p from ~200 images per batch (+17 % slower at 64 images = 77,000
     // sub-sequences, +9 % at 128, -10 % at 256 = 307,000 and beyond), 8192 x 8192 from ~20 (+41 % for one image = 58,000,
-    // +1 % at 16 = 925,000, -6 % at 32, -11 % at 64): big images need more (their per-image steps -- prefix scan, lists --
-    // are serial), hence the two-part rule.
+    // -2 % at 16 = 925,000, -7 % at 24, -11 % at 64), 4096 x 4096 from ~30 (+12 % at 16 = 231,000, -6 % at 48): the larger
+    // the images the more stream it takes (their per-image steps -- lists, index -- are serial), hence the three-step rule.
     bool fz_now = b->fused;
     if (fz_now && !b->fused_always) {
         uint64_t subs = 0, nfz = 0;
         for (int i = 0; i < n; i++)
             if (b->fz_ok[i]) { subs += ((uint64_t)b->img[i].ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS; nfz++; }
-        fz_now = nfz && (subs >= 900000 || (subs >= 250000 && subs / nfz <= 4096));
+        const uint64_t avg = nfz ? subs / nfz : 0;
+        fz_now = nfz && subs >= (avg <= 4096 ? 250000u : avg <= 20000 ? 450000u : 800000u);
     }
     for (int i = 0; i < n; i++) {
         JdImg& im = b->img[i];
