@@ -2724,10 +2724,13 @@ void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
-    const uint32_t lds = lb + (round < 0 ? JD_W_WAVES : JD_F_REDO_LANES / 64u) * JD_WAVE_LDS;
+    // lanes per workgroup: the first decode fills eight waves; round 0's lists (one sub-sequence in twelve) still fill a few;
+    // later lists are a handful of entries per image -- one wave, so that a CU holds eight such workgroups, not three
+    const uint32_t lanes = round < 0 ? 64u * JD_W_WAVES : round == 0 ? JD_F_REDO_LANES : 64u;
+    const uint32_t lds = lb + (lanes / 64u) * JD_WAVE_LDS;
     if (lb + JD_W_WAVES * JD_WAVE_LDS > 64u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1f_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb + JD_W_WAVES * JD_WAVE_LDS));
-    hipLaunchKernelGGL(k1f_write, dim3(wgs), dim3(round < 0 ? 64 * JD_W_WAVES : JD_F_REDO_LANES), lds, s, x, lb, round);
+    hipLaunchKernelGGL(k1f_write, dim3(wgs), dim3(lanes), lds, s, x, lb, round);
 }
 void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s) {
     if (!wgs) return;
