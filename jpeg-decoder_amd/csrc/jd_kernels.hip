@@ -1770,6 +1770,9 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
     const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
     const uint32_t s = lw * JD_F_LANES + threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t total = im.n_mcus * im.bpm, bpm = im.bpm, nl = im.hs * im.vs, ch0 = im.f_ch0, ovb = im.f_ov_base;
+    // x mod bpm for x < 6000 (a sub-sequence holds at most 4096 blocks) as x - bpm * ((x * M) >> 16), M = ceil(2^16 / bpm):
+    // exact while x * (M * bpm - 2^16) < 2^16.  (The kernel is bound by its vector instructions, and `%` was a third of them.)
+    const uint32_t mod_m = (65536u + bpm - 1u) / bpm;
     uint32_t nb = 0, c = 0, blk0 = 0, par = 0;
     int d0 = 0, d1 = 0, d2 = 0;
     if (s < nsub) {
@@ -1804,7 +1807,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
             uint32_t slot;
             if (j < ch0 - 2u) slot = s_i * ch0 + par_i + j;
             else { const uint32_t o = j - (ch0 - 2u), k = o / (JD_F_CHUNK - 2u); slot = ovb + ctab[k] * JD_F_CHUNK + par_i + (o - k * (JD_F_CHUNK - 2u)); }
-            const uint32_t cb = (c_i + j) % bpm;
+            const uint32_t xj = c_i + j, cb = xj - bpm * ((xj * mod_m) >> 16);
             const uint32_t comp = cb < nl ? 0u : cb - nl + 1u;
             out[j] = make_uint2(slot, (uint32_t)(comp == 0u ? e0 : comp == 1u ? e1 : e2));
         }
