@@ -17,9 +17,13 @@ HERE = os.path.dirname(__file__)
 REF = os.path.join(HERE, "golden", "ref_test")
 
 
-def test_c5_batch_1080p_against_oracle():
+@pytest.mark.parametrize("nodri_path", [2, 0])
+def test_c5_batch_1080p_against_oracle(nodri_path, monkeypatch):
     """One batch: 64 distinct 1920x1080 4:2:0 no-DRI images plus DRI and 4:2:2 / 4:4:0 frames of the same size; every
-    image's coefficients AND pixels bit-exact against the oracle (DRI files: the oracle decodes the no-DRI twin, F3)."""
+    image's coefficients AND pixels bit-exact against the oracle (DRI files: the oracle decodes the no-DRI twin, F3).
+    Once through each no-DRI path (JD_NODRI_FUSED: 2 = single decode, 0 = two passes; by size this batch would take the
+    second)."""
+    monkeypatch.setenv("JD_NODRI_FUSED", str(nodri_path))
     specs = [(2, 2, 0, s) for s in range(64)] + [(2, 2, 8, 64), (2, 2, 120, 65), (2, 1, 0, 66), (1, 2, 0, 67), (2, 1, 5, 68)]
     files, twins = [], []
     for hs, vs, ri, seed in specs:
@@ -40,20 +44,27 @@ def test_c5_batch_1080p_against_oracle():
     b.close()
 
 
-def test_c3_c4_full_size_against_oracle():
+def test_c3_c4_full_size_against_oracle(monkeypatch):
     """BASELINE size (8192 x 8192, 4:2:0): coefficients equal the encoder's own; the RGB of the DRI-8 file (C3) and of its
-    no-DRI twin (C4) both equal the oracle's decode of the twin, all 201 MB of it."""
+    no-DRI twin (C4) both equal the oracle's decode of the twin, all 201 MB of it -- the twin through both no-DRI paths
+    (a single image takes the two-pass path by size; the bench's 64-image batches take the single-decode path)."""
     im = jd.SynthImage(8192, 8192, 2, 2, 3, quality=85, seed=0, detail=2)
     dri, twin = im.encode(8), im.encode(0)
     want_c = im.coefficients()
     assert np.array_equal(jd.decode_coefficients(dri), want_c)
     assert np.array_equal(jd.decode_coefficients(twin), want_c)
+    monkeypatch.setenv("JD_NODRI_FUSED", "2")
+    assert np.array_equal(jd.decode_coefficients(twin), want_c), "C4, single-decode path: coefficients"
+    monkeypatch.delenv("JD_NODRI_FUSED")
     del want_c
     want = orclib.OracleImage(twin).rgb
     got = jd.decode_jpeg(dri)
     assert np.array_equal(got, want), "C3: %d pixels differ" % int((got != want).any(axis=2).sum())
     got = jd.decode_jpeg(twin)
     assert np.array_equal(got, want), "C4: %d pixels differ" % int((got != want).any(axis=2).sum())
+    monkeypatch.setenv("JD_NODRI_FUSED", "2")
+    got = jd.decode_jpeg(twin)
+    assert np.array_equal(got, want), "C4, single-decode path: %d pixels differ" % int((got != want).any(axis=2).sum())
 
 
 @pytest.mark.parametrize("name", ["cat0-q.jpg", "cat1.jpg", "cat0-h.jpg"])
