@@ -383,6 +383,7 @@ int refresh(jd_batch* b, hipStream_t s) {
         const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
         im.n_k0_chunks = stuffed ? (uint32_t)((im.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK) : 0;
         const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
+        const uint32_t nsub_f = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_F_SUBSEQ_BITS - 1) / JD_F_SUBSEQ_BITS);   // single-decode path
         if (fz_now && b->fz_ok[i]) im.flags |= JD_IMG_FUSED; else im.flags &= ~(uint32_t)JD_IMG_FUSED;
         const bool fz = (im.flags & JD_IMG_FUSED) != 0;
         const uint32_t nsw = (im.restart_interval || fz) ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_OWN - 1) / JD_SYNC_OWN);
@@ -392,14 +393,14 @@ int refresh(jd_batch* b, hipStream_t s) {
         pre[2][i + 1] = pre[2][i] + nsw;
         pre[3][i + 1] = pre[3][i] + (nsw * JD_SYNC_WG + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES);
         pre[4][i + 1] = pre[4][i] + im.n_tiles;
-        const uint32_t fwg = fz ? std::min(im.n_fwg, (nsub + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES)) : 0;
-        if (fz && nsub > 8192) b->fscan_tiled = 1;
+        const uint32_t fwg = fz ? std::min(im.n_fwg, (nsub_f + 64 * JD_W_WAVES - 1) / (64 * JD_W_WAVES)) : 0;
+        if (fz && nsub_f > 8192) b->fscan_tiled = 1;
         pre[5][i + 1] = pre[5][i] + fwg;
-        pre[6][i + 1] = pre[6][i] + (fz ? (nsub + JD_F_REDO_LANES * JD_F_REDO_DIV - 1) / (JD_F_REDO_LANES * JD_F_REDO_DIV) : 0);
+        pre[6][i + 1] = pre[6][i] + (fz ? (nsub_f + JD_F_REDO_LANES * JD_F_REDO_DIV - 1) / (JD_F_REDO_LANES * JD_F_REDO_DIV) : 0);
         if (fz) {
             // slots every sub-sequence owns: a quarter more than the average it will hold (the stuffed length bounds the
             // number of sub-sequences from above); the overflow chunks start behind them
-            const uint64_t nb = (uint64_t)im.n_mcus * im.bpm, ns = std::max<uint32_t>(nsub, 1);
+            const uint64_t nb = (uint64_t)im.n_mcus * im.bpm, ns = std::max<uint32_t>(nsub_f, 1);
             uint64_t ch0 = ((nb + nb / 4) / ns + 8 + 7) & ~(uint64_t)7;
             { const int dbg = env_int("JD_DEBUG_FUSED_CH0", 0); if (dbg > 0) ch0 = std::max<uint64_t>((uint64_t)dbg & ~(uint64_t)1, 4); }   // tests: small runs, many overflow chunks
             if (ch0 * ns > fused_own_budget(nb, im.n_subseq_cap)) ch0 = 8;   // (cannot happen: ns <= n_subseq_cap)
@@ -651,7 +652,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                 for (uint32_t l = 16; l >= 1; l--) { if (f.huff[0][f.comp[c].td].bits[l - 1]) ld = l; if (f.huff[1][f.comp[c].ta].bits[l - 1]) la = l; }
                 minbits = std::min(minbits, ld + la);
             }
-            const uint32_t kmax = (JD_SUBSEQ_BITS / minbits + 1 + JD_F_CHUNK - 3) / (JD_F_CHUNK - 2) + 1;
+            const uint32_t kmax = (JD_F_SUBSEQ_BITS / minbits + 1 + JD_F_CHUNK - 3) / (JD_F_CHUNK - 2) + 1;
             b->fkmax = std::max(b->fkmax, std::min<uint32_t>(kmax, JD_F_KMAX_LIMIT));
         } else coef += (size_t)im.n_mcus * im.bpm * 64;
         k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);

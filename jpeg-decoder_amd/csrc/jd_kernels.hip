@@ -1185,8 +1185,9 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     auto ring_at = [&](uint32_t xb) { return lds_u32(ring_l | (xb & (JD_SPEC_RING_BYTES - 1u))); };
     const uint32_t dcs_l = JD_SY_DCSUM + threadIdx.x * 4u;
     // stream position: bit `start` of the unstuffed stream; data begins at quad 1 (front pad)
-    uint32_t end = (s + 1u) * JD_SUBSEQ_BITS; if (end > sbits) end = sbits;
-    uint32_t start = s * JD_SUBSEQ_BITS + (entry & 0xFFu);
+    constexpr uint32_t kSubBits = MODE == 3 ? JD_F_SUBSEQ_BITS : JD_SUBSEQ_BITS;   // (the single-decode path has its own size)
+    uint32_t end = (s + 1u) * kSubBits; if (end > sbits) end = sbits;
+    uint32_t start = s * kSubBits + (entry & 0xFFu);
     if (COLD && end - start > JD_COLD_BITS) start = end - JD_COLD_BITS;
     const uint32_t o0 = ((start - 1u) & 31u) + 1u;
     const uint32_t g = ((start + 32u - o0) >> 5) + 3u;                    // dword (front pad included) that becomes w0
@@ -1249,7 +1250,7 @@ __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint
     int matched = -1;
     if (MODE == 2 && run && use_ck) tgt = ck->e[0].state;
     // (MODE 3 gives up a sub-sequence's length past the end: garbage that never completes a block is just a wrong guess)
-    while (left > 0 || (MODE == 3 && z != 0u && left > -(int)JD_SUBSEQ_BITS)) {
+    while (left > 0 || (MODE == 3 && z != 0u && left > -(int)JD_SUBSEQ_BITS)) {   // (a block is < 2000 bits)
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rpb >= wqb) != 0, 0)) top_up();
         const uint32_t cand = ring_at(rpb);
         const uint32_t win = __builtin_amdgcn_alignbit(w0, w1, sh);
@@ -1557,7 +1558,7 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1f_cold(JdKernelArgs a) {
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
-    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
     if (lw * JD_F_LANES + 1u >= nsub) return;                  // (the last sub-sequence's exit is nobody's entry)
     const ImgK ik = load_imgk(im);
     if (threadIdx.x < 16u) {
@@ -1588,7 +1589,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, 
     const uint32_t wg_lanes = blockDim.x;                       // 64 * JD_W_WAVES for the first decode, JD_F_REDO_LANES for the lists
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
-    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
     const uint32_t n_todo = round < 0 ? nsub : a.fcount[(uint32_t)round * (uint32_t)a.n_images + (uint32_t)img];
     if (lw * wg_lanes >= n_todo) return;                      // whole workgroup idle (uniform)
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
@@ -1615,8 +1616,8 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, 
             fs.slot0 = s * im.f_ch0;
             const uint32_t c0 = (fs.entry >> 16) & 0xFFu;
             fs.c0 = c0 < im.bpm ? c0 : 0u;
-            sg.end_bit = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
-            sg.start_bit = s * JD_SUBSEQ_BITS + (fs.entry & 0xFFFFu);
+            sg.end_bit = (s + 1u) * JD_F_SUBSEQ_BITS < sbits ? (s + 1u) * JD_F_SUBSEQ_BITS : sbits;
+            sg.start_bit = s * JD_F_SUBSEQ_BITS + (fs.entry & 0xFFFFu);
             if (sg.start_bit > sbits) sg.start_bit = sbits;          // (a block cannot start past the data; the walk then has nothing to do)
         }
         write_segments8<true, true>(a, im, img, lut_bytes, sg, slen, 0u, &fs);
@@ -1633,7 +1634,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_check(JdKernelArgs a, int
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
     const uint32_t s = lw * JD_F_LANES + threadIdx.x;
     bool redo = false;
     if (s < nsub) redo = a.sub[im.subseq_base + s].entry != (s ? a.sub[im.subseq_base + s - 1u].exit : JD_FSTATE(0u, 0u));
@@ -1685,7 +1686,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_scan(JdKernelArgs a) {
     if (lw % JD_F_SCAN_PER) return;
     const uint32_t tile = lw / JD_F_SCAN_PER;
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
     const uint32_t tile_subs = JD_F_LANES * JD_F_SCAN_PER;
     if (tile * tile_subs >= nsub && tile) return;               // (tile 0 always runs: it reports an empty stream)
     uint4* const tile_tot = a.sync_tot + im.sync_wg_base;
@@ -1738,7 +1739,7 @@ __global__ __launch_bounds__(1024) void k1f_scan_img(JdKernelArgs a) {
     const JdImg& im = a.imgs[img];
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
     uint4 run = make_uint4(0, 0, 0, 0);
     for (uint32_t s0 = 0; s0 < nsub; s0 += 1024u) {
         const uint32_t s = s0 + threadIdx.x;
@@ -1767,12 +1768,12 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_SUBSEQ_BITS - 1u) / JD_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
     const uint32_t s = lw * JD_F_LANES + threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t total = im.n_mcus * im.bpm, bpm = im.bpm, nl = im.hs * im.vs, ch0 = im.f_ch0, ovb = im.f_ov_base;
-    // x mod bpm for x < 6000 (a sub-sequence holds at most 4096 blocks) as x - bpm * ((x * M) >> 16), M = ceil(2^16 / bpm):
-    // exact while x * (M * bpm - 2^16) < 2^16.  (The kernel is bound by its vector instructions, and `%` was a third of them.)
-    const uint32_t mod_m = (65536u + bpm - 1u) / bpm;
+    // x mod bpm as x - bpm * mulhi(x, M), M = ceil(2^32 / bpm): exact while x * (M * bpm - 2^32) < 2^32, i.e. for every
+    // x < 2^32 / bpm (bpm = 1: M does not fit, and the answer is 0 anyway)
+    const uint32_t mod_m = bpm > 1u ? (uint32_t)((0x100000000ull + bpm - 1u) / bpm) : 0u;
     uint32_t nb = 0, c = 0, blk0 = 0, par = 0;
     int d0 = 0, d1 = 0, d2 = 0;
     if (s < nsub) {
@@ -1788,7 +1789,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
             if (nb == r.nstart) err |= r.first & 0xFFu;                   // errors in blocks the frame has
             else if ((r.first >> 16) < nb) err |= (r.first >> 8) & 0xFFu;
             // a block the frame needs ran past the end of the data
-            const uint32_t end_s = (s + 1u) * JD_SUBSEQ_BITS < sbits ? (s + 1u) * JD_SUBSEQ_BITS : sbits;
+            const uint32_t end_s = (s + 1u) * JD_F_SUBSEQ_BITS < sbits ? (s + 1u) * JD_F_SUBSEQ_BITS : sbits;
             if (nb == r.nstart && end_s + (r.exit & 0xFFFFu) > sbits) err |= JD_ST_TRUNC;
             if (err) atomicOr(&a.status[img], err);
         }
@@ -1807,7 +1808,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
             uint32_t slot;
             if (j < ch0 - 2u) slot = s_i * ch0 + par_i + j;
             else { const uint32_t o = j - (ch0 - 2u), k = o / (JD_F_CHUNK - 2u); slot = ovb + ctab[k] * JD_F_CHUNK + par_i + (o - k * (JD_F_CHUNK - 2u)); }
-            const uint32_t xj = c_i + j, cb = xj - bpm * ((xj * mod_m) >> 16);
+            const uint32_t xj = c_i + j, cb = xj - bpm * __umulhi(xj, mod_m);
             const uint32_t comp = cb < nl ? 0u : cb - nl + 1u;
             out[j] = make_uint2(slot, (uint32_t)(comp == 0u ? e0 : comp == 1u ? e1 : e2));
         }
