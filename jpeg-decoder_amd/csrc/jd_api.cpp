@@ -32,7 +32,7 @@ void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s);
 void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, int16_t* d_out, hipStream_t s);
 void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
-void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, hipStream_t s);
+void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, uint32_t lanes0, hipStream_t s);
 void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s);
 void jdk_launch_fscan_index(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int tiled, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
@@ -293,6 +293,7 @@ struct jd_batch {
     uint2* d_loc = nullptr; uint32_t *d_chunk = nullptr, *d_guess = nullptr, *d_wl = nullptr, *d_falloc = nullptr, *d_fhalloc = nullptr, *d_fcount = nullptr;
     uint32_t fkmax = 0, wg_f = 0, wg_fr = 0;
     int fscan_tiled = 0;                        // some image has more than 8192 sub-sequences: prefix scan in tiles
+    uint32_t redo0_lanes = JD_F_REDO_LANES;     // workgroup size of the first re-decode round (by the images' list lengths)
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
     bool fused_always = false;                 // JD_NODRI_FUSED=2: whatever the batch's size (tests)
     std::vector<uint8_t> fz_ok;                // per image: planned for the single-decode path (staging allocated)
@@ -411,6 +412,12 @@ int refresh(jd_batch* b, hipStream_t s) {
     b->wg_k0 = pre[0][n]; b->wg_iv = pre[1][n]; b->wg_sync = pre[2][n]; b->wg_wr = pre[3][n]; b->wg_tile = pre[4][n]; b->wg_f = pre[5][n]; b->wg_fr = pre[6][n];
     // blind re-decode rounds: what a round leaves shrinks by an order of magnitude, so a small batch needs fewer (each is
     // two launches on the critical path; jd_batch_wait finishes what a last check still finds)
+    {   // the first round's list holds about a twelfth of an image's sub-sequences
+        uint64_t subs_f = 0, nfz2 = 0;
+        for (int i = 0; i < n; i++) if (b->img[i].flags & JD_IMG_FUSED) { subs_f += ((uint64_t)b->img[i].ecs_len * 8 + JD_F_SUBSEQ_BITS - 1) / JD_F_SUBSEQ_BITS; nfz2++; }
+        const uint64_t est = nfz2 ? subs_f / nfz2 / 12 : 0;
+        b->redo0_lanes = est <= 48 ? 64u : est <= 110 ? 128u : JD_F_REDO_LANES;
+    }
     if (b->fused_rounds_env < 0) b->fused_rounds = (uint64_t)b->wg_f * 64 * JD_W_WAVES < 200000 ? 3 : JD_F_ROUNDS;
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc, b->desc_bytes, hipMemcpyHostToDevice, s));
     if (b->ev_desc) HIPCHK(hipEventRecord(b->ev_desc, s));
@@ -451,10 +458,10 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
             // the writing decode from the blind guesses, then JD_F_ROUNDS rounds of "list the sub-sequences whose entry is
             // not their predecessor's exit, decode those again" (the first redoes one in twelve, the rest next to nothing),
             // a last check for jd_batch_wait, the prefix scan and the block index
-            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, s);
+            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, 0, s);
             for (int r = 0; r < b->fused_rounds; r++) {
                 jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, r, s);
-                jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, s);
+                jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, b->redo0_lanes, s);
             }
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
             jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, b->fscan_tiled, s);
@@ -836,7 +843,7 @@ int wait_on(jd_batch* b) {
         // single-decode path: the last check left a list; decode it, check again, until a check finds nothing
         guard = 0;
         if (more_f) do {
-            jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, JD_F_ROUNDS, s);
+            jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, JD_F_ROUNDS, 64, s);
             HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
             HIPCHK(hipMemsetAsync(b->d_fcount + (size_t)JD_F_ROUNDS * b->n, 0, (size_t)b->n * sizeof(uint32_t), s));
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);

@@ -1808,7 +1808,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
             uint32_t slot;
             if (j < ch0 - 2u) slot = s_i * ch0 + par_i + j;
             else { const uint32_t o = j - (ch0 - 2u), k = o / (JD_F_CHUNK - 2u); slot = ovb + ctab[k] * JD_F_CHUNK + par_i + (o - k * (JD_F_CHUNK - 2u)); }
-            const uint32_t xj = c_i + j, cb = xj - bpm * __umulhi(xj, mod_m);
+            const uint32_t xj = c_i + j, cb = bpm > 1u ? xj - bpm * __umulhi(xj, mod_m) : 0u;
             const uint32_t comp = cb < nl ? 0u : cb - nl + 1u;
             out[j] = make_uint2(slot, (uint32_t)(comp == 0u ? e0 : comp == 1u ? e1 : e2));
         }
@@ -2724,13 +2724,15 @@ void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t 
     hipLaunchKernelGGL(k1f_cold, dim3(wgs), dim3(JD_SYNC_WG), JD_SY_LUT + lb, s, x);
 }
 // round < 0: every sub-sequence; round >= 0: the sub-sequences k1f_check listed for that round
-void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, hipStream_t s) {
+// lanes0: workgroup size of round 0 (64 / 128 / JD_F_REDO_LANES, by how long an image's first list will be)
+void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, uint32_t lanes0, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
-    // lanes per workgroup: the first decode fills eight waves; round 0's lists (one sub-sequence in twelve) still fill a few;
-    // later lists are a handful of entries per image -- one wave, so that a CU holds eight such workgroups, not three
-    const uint32_t lanes = round < 0 ? 64u * JD_W_WAVES : round == 0 ? JD_F_REDO_LANES : 64u;
+    // lanes per workgroup: the first decode fills eight waves; round 0's lists (one sub-sequence in twelve) fill one to
+    // four; later lists are a handful of entries per image -- one wave, so that a CU holds eight such workgroups, not
+    // three (a workgroup's LDS is the tables + 8 KB per wave, and these launches are bound by how many walks run at once)
+    const uint32_t lanes = round < 0 ? 64u * JD_W_WAVES : round == 0 ? lanes0 : 64u;
     const uint32_t lds = lb + (lanes / 64u) * JD_WAVE_LDS;
     if (lb + JD_W_WAVES * JD_WAVE_LDS > 64u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1f_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb + JD_W_WAVES * JD_WAVE_LDS));
