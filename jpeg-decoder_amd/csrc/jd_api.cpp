@@ -293,6 +293,7 @@ struct jd_batch {
     uint2* d_loc = nullptr; uint32_t *d_chunk = nullptr, *d_guess = nullptr, *d_wl = nullptr, *d_falloc = nullptr, *d_fhalloc = nullptr, *d_fcount = nullptr;
     uint32_t fkmax = 0, wg_f = 0, wg_fr = 0;
     int fscan_tiled = 0;                        // some image has more than 8192 sub-sequences: prefix scan in tiles
+    uint32_t fsub_bits = JD_SUBSEQ_BITS;        // sub-sequence size of the single-decode path in this run (by the batch's size)
     uint32_t redo0_lanes = JD_F_REDO_LANES;     // workgroup size of the first re-decode round (by the images' list lengths)
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
     bool fused_always = false;                 // JD_NODRI_FUSED=2: whatever the batch's size (tests)
@@ -340,7 +341,7 @@ JdKernelArgs kernel_args(const jd_batch* b) {
     a.imgs = b->d_img; a.n_images = b->n; a.prefix = nullptr; a.stream = b->d_stream; a.coef = b->d_coef;
     a.lut = b->d_lut; a.status = b->d_status; a.stream_len = b->d_stream_len; a.interval_start = b->d_interval;
     a.k0_state = b->d_k0; a.k0_ticket = b->d_ticket; a.sub = b->d_sub; a.subpfx = b->d_subpfx; a.subck = b->d_subck; a.sync_tot = b->d_sync_tot; a.changed = b->d_changed;
-    a.loc = b->d_loc; a.chunk = b->d_chunk; a.guess = b->d_guess; a.wl = b->d_wl; a.falloc = b->d_falloc; a.fhalloc = b->d_fhalloc; a.fcount = b->d_fcount; a.fkmax = b->fkmax;
+    a.loc = b->d_loc; a.chunk = b->d_chunk; a.guess = b->d_guess; a.wl = b->d_wl; a.falloc = b->d_falloc; a.fhalloc = b->d_fhalloc; a.fcount = b->d_fcount; a.fkmax = b->fkmax; a.fsub_bits = b->fsub_bits;
     return a;
 }
 
@@ -378,13 +379,16 @@ int refresh(jd_batch* b, hipStream_t s) {
             if (b->fz_ok[i]) { subs += ((uint64_t)b->img[i].ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS; nfz++; }
         const uint64_t avg = nfz ? subs / nfz : 0;
         fz_now = nfz && subs >= (avg <= 4096 ? 250000u : avg <= 20000 ? 450000u : 800000u);
-    }
+        // ... and with long sub-sequences once the batch is larger still (8192 bits beat 4096 from ~900,000: 512 x 1080p
+        // -13 % against -11 %, 16 x 8192^2 -7 % against -2 %; below, 48 x 4096^2 +1 % against -7 %; at C4 / C5 size -17 % against -11 %)
+        b->fsub_bits = subs >= (uint64_t)env_int("JD_DEBUG_FUSED_LONG_FROM", 900000) ? JD_F_SUBSEQ_BITS_MAX : JD_SUBSEQ_BITS;
+    } else b->fsub_bits = env_int("JD_DEBUG_FUSED_LONG_FROM", 1) == 0 ? JD_F_SUBSEQ_BITS_MAX : JD_SUBSEQ_BITS;
     for (int i = 0; i < n; i++) {
         JdImg& im = b->img[i];
         const bool stuffed = !(im.flags & JD_IMG_UNSTUFFED_INPUT);
         im.n_k0_chunks = stuffed ? (uint32_t)((im.ecs_len + JD_K0_CHUNK - 1) / JD_K0_CHUNK) : 0;
         const uint32_t nsub = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS);
-        const uint32_t nsub_f = (uint32_t)(((uint64_t)im.ecs_len * 8 + JD_F_SUBSEQ_BITS - 1) / JD_F_SUBSEQ_BITS);   // single-decode path
+        const uint32_t nsub_f = (uint32_t)(((uint64_t)im.ecs_len * 8 + b->fsub_bits - 1) / b->fsub_bits);   // single-decode path
         if (fz_now && b->fz_ok[i]) im.flags |= JD_IMG_FUSED; else im.flags &= ~(uint32_t)JD_IMG_FUSED;
         const bool fz = (im.flags & JD_IMG_FUSED) != 0;
         const uint32_t nsw = (im.restart_interval || fz) ? 0 : std::min(im.n_sync_wg, (nsub + JD_SYNC_OWN - 1) / JD_SYNC_OWN);
@@ -414,7 +418,7 @@ int refresh(jd_batch* b, hipStream_t s) {
     // two launches on the critical path; jd_batch_wait finishes what a last check still finds)
     {   // the first round's list holds about a twelfth of an image's sub-sequences
         uint64_t subs_f = 0, nfz2 = 0;
-        for (int i = 0; i < n; i++) if (b->img[i].flags & JD_IMG_FUSED) { subs_f += ((uint64_t)b->img[i].ecs_len * 8 + JD_F_SUBSEQ_BITS - 1) / JD_F_SUBSEQ_BITS; nfz2++; }
+        for (int i = 0; i < n; i++) if (b->img[i].flags & JD_IMG_FUSED) { subs_f += ((uint64_t)b->img[i].ecs_len * 8 + b->fsub_bits - 1) / b->fsub_bits; nfz2++; }
         const uint64_t est = nfz2 ? subs_f / nfz2 / 12 : 0;
         b->redo0_lanes = est <= 48 ? 64u : est <= 110 ? 128u : JD_F_REDO_LANES;
     }
@@ -659,7 +663,7 @@ int batch_build(int device, int n_images, const jd_frame* frames, const size_t* 
                 for (uint32_t l = 16; l >= 1; l--) { if (f.huff[0][f.comp[c].td].bits[l - 1]) ld = l; if (f.huff[1][f.comp[c].ta].bits[l - 1]) la = l; }
                 minbits = std::min(minbits, ld + la);
             }
-            const uint32_t kmax = (JD_F_SUBSEQ_BITS / minbits + 1 + JD_F_CHUNK - 3) / (JD_F_CHUNK - 2) + 1;
+            const uint32_t kmax = (JD_F_SUBSEQ_BITS_MAX / minbits + 1 + JD_F_CHUNK - 3) / (JD_F_CHUNK - 2) + 1;
             b->fkmax = std::max(b->fkmax, std::min<uint32_t>(kmax, JD_F_KMAX_LIMIT));
         } else coef += (size_t)im.n_mcus * im.bpm * 64;
         k0c += (uint32_t)((ecs_cap[i] + JD_K0_CHUNK - 1) / JD_K0_CHUNK);

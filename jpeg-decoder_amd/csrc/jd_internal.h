@@ -128,14 +128,14 @@ enum {
 // reads coefficients through that.  Decodes per bit: 0.5 (blind) + 1 + 0.1.
 // Sub-sequence state here: the first block START at or after a sub-sequence's end, as [15:0] its bit offset past that
 // end, [23:16] its block-in-MCU index.
-// Its sub-sequences are twice the two-pass path's: the blind decode costs the same 2048 bits per BOUNDARY, so half as many
-// boundaries halve it; a wrong guess wastes the same share of the work either way.
-#ifndef JD_F_SUBSEQ_BITS
-#define JD_F_SUBSEQ_BITS 8192u
-#endif
+// Its sub-sequences are the two-pass path's or twice that (JdKernelArgs::fsub_bits, chosen per run by the batch's size):
+// the blind decode costs the same 2048 bits per BOUNDARY, so half as many boundaries halve it, and a wrong guess wastes the
+// same share of the work either way -- but every step of the critical path is one walk through a sub-sequence, so only a
+// batch that fills the machine many times over takes the long ones.
+#define JD_F_SUBSEQ_BITS_MAX 8192u
 #define JD_F_CHUNK 32u
 #define JD_F_ROUNDS 6              // re-decode rounds enqueued blindly; jd_batch_wait adds more while the last check finds work
-#define JD_F_KMAX_LIMIT (JD_F_SUBSEQ_BITS / 2u / (JD_F_CHUNK - 2u) + 4u)   // chunk-table entries per sub-sequence: a block is at least two bits
+#define JD_F_KMAX_LIMIT (JD_F_SUBSEQ_BITS_MAX / 2u / (JD_F_CHUNK - 2u) + 4u)   // chunk-table entries per sub-sequence: a block is at least two bits
 #define JD_F_HIMAP_OFF(slot_cap) ((uint64_t)(slot_cap) * 64u)                                   // byte offsets in the image's region
 #define JD_F_HIPOOL_OFF(slot_cap) (JD_F_HIMAP_OFF(slot_cap) + ((((uint64_t)(slot_cap) * 4u) + 63u) & ~(uint64_t)63u))
 #ifndef JD_F_CUT_DIV
@@ -258,5 +258,6 @@ struct JdKernelArgs {
     uint32_t* fhalloc;           // per image: high-part slots handed out
     uint32_t* fcount;            // [JD_F_ROUNDS + 1][n_images]: length of the re-decode list of each round
     uint32_t fkmax;
+    uint32_t fsub_bits;          // bits per sub-sequence of the single-decode path in this run (4096 or 8192)
 };
 

@@ -1178,14 +1178,14 @@ __device__ __forceinline__ void ck_store(JdCkEntry* e, uint32_t state, uint32_t 
 template <int MODE>
 __device__ __forceinline__ void spec_decode(const ImgK& ik, const uint4* Q, uint32_t qmax, const uint16_t* __restrict__ lutg,
                                             uint32_t s, uint32_t entry, uint32_t sbits, bool run, JdSub& rec,
-                                            JdSubCk* __restrict__ ck = nullptr, bool use_ck = false) {
+                                            JdSubCk* __restrict__ ck = nullptr, bool use_ck = false, uint32_t fsub_bits = 0) {
     constexpr bool COLD = MODE == 0 || MODE == 3;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ring_l = JD_SY_RINGS + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * JD_SPEC_RING_BYTES + lane * 4u;
     auto ring_at = [&](uint32_t xb) { return lds_u32(ring_l | (xb & (JD_SPEC_RING_BYTES - 1u))); };
     const uint32_t dcs_l = JD_SY_DCSUM + threadIdx.x * 4u;
     // stream position: bit `start` of the unstuffed stream; data begins at quad 1 (front pad)
-    constexpr uint32_t kSubBits = MODE == 3 ? JD_F_SUBSEQ_BITS : JD_SUBSEQ_BITS;   // (the single-decode path has its own size)
+    const uint32_t kSubBits = MODE == 3 ? fsub_bits : JD_SUBSEQ_BITS;   // (the single-decode path has its own size, set per run)
     uint32_t end = (s + 1u) * kSubBits; if (end > sbits) end = sbits;
     uint32_t start = s * kSubBits + (entry & 0xFFu);
     if (COLD && end - start > JD_COLD_BITS) start = end - JD_COLD_BITS;
@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1f_cold(JdKernelArgs a) {
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
-    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + a.fsub_bits - 1u) / a.fsub_bits;
     if (lw * JD_F_LANES + 1u >= nsub) return;                  // (the last sub-sequence's exit is nobody's entry)
     const ImgK ik = load_imgk(im);
     if (threadIdx.x < 16u) {
@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1f_cold(JdKernelArgs a) {
         if (__builtin_amdgcn_readfirstlane(lw * JD_F_LANES + h * JD_SYNC_WG + (threadIdx.x & ~63u)) + 1u >= nsub) continue;   // wave-uniform
         const bool run = s + 1u < nsub;
         JdSub rec; rec.entry = rec.exit = 0; rec.nstart = 0; rec.first = 0; rec.dc[0] = rec.dc[1] = rec.dc[2] = 0; rec.pad = 0;
-        spec_decode<3>(ik, Q, qmax, a.lut + im.lut_off, run ? s : 0u, pack_state(0, 0, 0), sbits, run, rec);
+        spec_decode<3>(ik, Q, qmax, a.lut + im.lut_off, run ? s : 0u, pack_state(0, 0, 0), sbits, run, rec, nullptr, false, a.fsub_bits);
         if (run) a.guess[im.subseq_base + s] = rec.exit;
     }
 }
@@ -1589,7 +1589,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, 
     const uint32_t wg_lanes = blockDim.x;                       // 64 * JD_W_WAVES for the first decode, JD_F_REDO_LANES for the lists
     const uint32_t slen = a.stream_len[img];
     const uint32_t sbits = slen * 8u;
-    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + a.fsub_bits - 1u) / a.fsub_bits;
     const uint32_t n_todo = round < 0 ? nsub : a.fcount[(uint32_t)round * (uint32_t)a.n_images + (uint32_t)img];
     if (lw * wg_lanes >= n_todo) return;                      // whole workgroup idle (uniform)
     load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
@@ -1616,8 +1616,8 @@ __global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, 
             fs.slot0 = s * im.f_ch0;
             const uint32_t c0 = (fs.entry >> 16) & 0xFFu;
             fs.c0 = c0 < im.bpm ? c0 : 0u;
-            sg.end_bit = (s + 1u) * JD_F_SUBSEQ_BITS < sbits ? (s + 1u) * JD_F_SUBSEQ_BITS : sbits;
-            sg.start_bit = s * JD_F_SUBSEQ_BITS + (fs.entry & 0xFFFFu);
+            sg.end_bit = (s + 1u) * a.fsub_bits < sbits ? (s + 1u) * a.fsub_bits : sbits;
+            sg.start_bit = s * a.fsub_bits + (fs.entry & 0xFFFFu);
             if (sg.start_bit > sbits) sg.start_bit = sbits;          // (a block cannot start past the data; the walk then has nothing to do)
         }
         write_segments8<true, true>(a, im, img, lut_bytes, sg, slen, 0u, &fs);
@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_check(JdKernelArgs a, int
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + a.fsub_bits - 1u) / a.fsub_bits;
     const uint32_t s = lw * JD_F_LANES + threadIdx.x;
     bool redo = false;
     if (s < nsub) redo = a.sub[im.subseq_base + s].entry != (s ? a.sub[im.subseq_base + s - 1u].exit : JD_FSTATE(0u, 0u));
@@ -1686,7 +1686,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_scan(JdKernelArgs a) {
     if (lw % JD_F_SCAN_PER) return;
     const uint32_t tile = lw / JD_F_SCAN_PER;
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + a.fsub_bits - 1u) / a.fsub_bits;
     const uint32_t tile_subs = JD_F_LANES * JD_F_SCAN_PER;
     if (tile * tile_subs >= nsub && tile) return;               // (tile 0 always runs: it reports an empty stream)
     uint4* const tile_tot = a.sync_tot + im.sync_wg_base;
@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(1024) void k1f_scan_img(JdKernelArgs a) {
     const JdImg& im = a.imgs[img];
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + a.fsub_bits - 1u) / a.fsub_bits;
     uint4 run = make_uint4(0, 0, 0, 0);
     for (uint32_t s0 = 0; s0 < nsub; s0 += 1024u) {
         const uint32_t s = s0 + threadIdx.x;
@@ -1768,7 +1768,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
     if (!(im.flags & JD_IMG_FUSED)) return;
     const uint32_t lw = blockIdx.x - a.prefix[img];
     const uint32_t sbits = a.stream_len[img] * 8u;
-    const uint32_t nsub = (sbits + JD_F_SUBSEQ_BITS - 1u) / JD_F_SUBSEQ_BITS;
+    const uint32_t nsub = (sbits + a.fsub_bits - 1u) / a.fsub_bits;
     const uint32_t s = lw * JD_F_LANES + threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t total = im.n_mcus * im.bpm, bpm = im.bpm, nl = im.hs * im.vs, ch0 = im.f_ch0, ovb = im.f_ov_base;
     // x mod bpm as x - bpm * mulhi(x, M), M = ceil(2^32 / bpm): exact while x * (M * bpm - 2^32) < 2^32, i.e. for every
@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(64 * JD_W_WAVES) void k1f_index(JdKernelArgs a) {
             if (nb == r.nstart) err |= r.first & 0xFFu;                   // errors in blocks the frame has
             else if ((r.first >> 16) < nb) err |= (r.first >> 8) & 0xFFu;
             // a block the frame needs ran past the end of the data
-            const uint32_t end_s = (s + 1u) * JD_F_SUBSEQ_BITS < sbits ? (s + 1u) * JD_F_SUBSEQ_BITS : sbits;
+            const uint32_t end_s = (s + 1u) * a.fsub_bits < sbits ? (s + 1u) * a.fsub_bits : sbits;
             if (nb == r.nstart && end_s + (r.exit & 0xFFFFu) > sbits) err |= JD_ST_TRUNC;
             if (err) atomicOr(&a.status[img], err);
         }

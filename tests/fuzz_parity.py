@@ -19,7 +19,7 @@ while time.time() - t0 < budget:
     elif os.environ.get("FUZZ_NODRI"):                  # stress the single-decode path: no restart markers, random knobs
         ri = 0
         for k, vals in (("JD_DEBUG_FUSED_ROUNDS", [None, None, 0, 1, 2]), ("JD_DEBUG_FUSED_CH0", [None, None, 4, 8, 24]),
-                        ("JD_DEBUG_FUSED_CAP_PERCENT", [None, None, None, 30]), ("JD_NODRI_FUSED", [2, 2, 2, 2, None, 0])):
+                        ("JD_DEBUG_FUSED_CAP_PERCENT", [None, None, None, 30]), ("JD_NODRI_FUSED", [2, 2, 2, 2, None, 0]), ("JD_DEBUG_FUSED_LONG_FROM", [None, 0, 0])):
             v = rng.choice(vals)
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = str(v)

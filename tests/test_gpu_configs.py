@@ -17,13 +17,14 @@ HERE = os.path.dirname(__file__)
 REF = os.path.join(HERE, "golden", "ref_test")
 
 
-@pytest.mark.parametrize("nodri_path", [2, 0])
-def test_c5_batch_1080p_against_oracle(nodri_path, monkeypatch):
+@pytest.mark.parametrize("nodri_path,long_from", [(2, 1), (2, 0), (0, 1)])
+def test_c5_batch_1080p_against_oracle(nodri_path, long_from, monkeypatch):
     """One batch: 64 distinct 1920x1080 4:2:0 no-DRI images plus DRI and 4:2:2 / 4:4:0 frames of the same size; every
     image's coefficients AND pixels bit-exact against the oracle (DRI files: the oracle decodes the no-DRI twin, F3).
     Once through each no-DRI path (JD_NODRI_FUSED: 2 = single decode, 0 = two passes; by size this batch would take the
     second)."""
     monkeypatch.setenv("JD_NODRI_FUSED", str(nodri_path))
+    monkeypatch.setenv("JD_DEBUG_FUSED_LONG_FROM", str(long_from))
     specs = [(2, 2, 0, s) for s in range(64)] + [(2, 2, 8, 64), (2, 2, 120, 65), (2, 1, 0, 66), (1, 2, 0, 67), (2, 1, 5, 68)]
     files, twins = [], []
     for hs, vs, ri, seed in specs:
@@ -55,7 +56,9 @@ def test_c3_c4_full_size_against_oracle(monkeypatch):
     assert np.array_equal(jd.decode_coefficients(twin), want_c)
     monkeypatch.setenv("JD_NODRI_FUSED", "2")
     assert np.array_equal(jd.decode_coefficients(twin), want_c), "C4, single-decode path: coefficients"
-    monkeypatch.delenv("JD_NODRI_FUSED")
+    monkeypatch.setenv("JD_DEBUG_FUSED_LONG_FROM", "0")
+    assert np.array_equal(jd.decode_coefficients(twin), want_c), "C4, single-decode path, 8192-bit sub-sequences: coefficients"
+    monkeypatch.delenv("JD_NODRI_FUSED"); monkeypatch.delenv("JD_DEBUG_FUSED_LONG_FROM")
     del want_c
     want = orclib.OracleImage(twin).rgb
     got = jd.decode_jpeg(dri)
@@ -63,8 +66,10 @@ def test_c3_c4_full_size_against_oracle(monkeypatch):
     got = jd.decode_jpeg(twin)
     assert np.array_equal(got, want), "C4: %d pixels differ" % int((got != want).any(axis=2).sum())
     monkeypatch.setenv("JD_NODRI_FUSED", "2")
-    got = jd.decode_jpeg(twin)
-    assert np.array_equal(got, want), "C4, single-decode path: %d pixels differ" % int((got != want).any(axis=2).sum())
+    for long_from in ("1", "0"):
+        monkeypatch.setenv("JD_DEBUG_FUSED_LONG_FROM", long_from)
+        got = jd.decode_jpeg(twin)
+        assert np.array_equal(got, want), "C4, single-decode path: %d pixels differ" % int((got != want).any(axis=2).sum())
 
 
 @pytest.mark.parametrize("name", ["cat0-q.jpg", "cat1.jpg", "cat0-h.jpg"])

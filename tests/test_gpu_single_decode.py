@@ -5,7 +5,8 @@ it replaces (JD_NODRI_FUSED=0) -- which stays the fallback and must stay correct
 The library picks the path per run by the batch's size (the single-decode path is the throughput path: jd_api.cpp,
 refresh()); the images here are small, so the tests force it.
 Knobs (read when a batch is created): JD_NODRI_FUSED=0 switches the path off, =2 takes it whatever the size; JD_DEBUG_FUSED_ROUNDS=n enqueues n blind
-re-decode rounds instead of 3, so that jd_batch_wait's loop has work; JD_DEBUG_FUSED_CAP_PERCENT=p gives the staging p % of
+re-decode rounds instead of 6, so that jd_batch_wait's loop has work; JD_DEBUG_FUSED_LONG_FROM=0 takes the path's long
+(8192-bit) sub-sequences whatever the batch's size; JD_DEBUG_FUSED_CAP_PERCENT=p gives the staging p % of
 the frame's blocks, so that it overflows and the batch falls back to the two-pass path."""
 import contextlib
 import os
@@ -43,10 +44,12 @@ GEOMETRIES = [(64, 48, 2, 2, 3), (333, 129, 2, 1, 3), (1040, 520, 1, 2, 3), (640
               (1920, 1080, 2, 2, 3), (801, 601, 1, 1, 1), (16, 16, 2, 2, 3), (8, 8, 1, 1, 1)]
 
 
-@pytest.mark.parametrize("fused", [2, 0])
+@pytest.mark.parametrize("fused,long_from", [(2, 1), (2, 0), (0, 1)])
 @pytest.mark.parametrize("w,h,hs,vs,nc", GEOMETRIES)
-def test_both_paths_against_the_oracle(w, h, hs, vs, nc, fused):
-    with knobs(JD_NODRI_FUSED=fused):
+def test_both_paths_against_the_oracle(w, h, hs, vs, nc, fused, long_from):
+    """the single-decode path with sub-sequences of 4096 and of 8192 bits (JD_DEBUG_FUSED_LONG_FROM=0: the long ones
+    whatever the batch's size), and the two-pass path"""
+    with knobs(JD_NODRI_FUSED=fused, JD_DEBUG_FUSED_LONG_FROM=long_from):
         for q, detail in ((85, 2), (50, 1), (92, 3)):
             _check(jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=w + q, detail=detail).encode(0))
 
@@ -55,7 +58,7 @@ def test_both_paths_against_the_oracle(w, h, hs, vs, nc, fused):
 def test_host_loop_finishes_what_blind_rounds_left(rounds):
     """no (or one) blind re-decode round: one sub-sequence in twelve starts from a wrong guess, the last check sees it and
     jd_batch_wait decodes, checks and re-indexes until nothing moves"""
-    with knobs(JD_DEBUG_FUSED_ROUNDS=rounds, JD_NODRI_FUSED=2):
+    with knobs(JD_DEBUG_FUSED_ROUNDS=rounds, JD_NODRI_FUSED=2, JD_DEBUG_FUSED_LONG_FROM=rounds):
         for seed, (w, h) in enumerate([(2048, 1024), (1920, 1080), (640, 360)]):
             _check(jd.SynthImage(w, h, 2, 2, 3, quality=90, seed=seed, detail=3).encode(0))
 
