@@ -6,7 +6,7 @@
 # two SQ passes (8 SQ counters each).  Every GPU step has its own time limit and the chain stops at the first failure.
 # Raw output goes to gpurun_out/<tag>/; summarise with profiles/summarise.py <tag>.
 set -e -o pipefail
-tag=${1:-r03_e}
+tag=${1:-r03_f}
 wls=${2:-"c3 c4 c5"}
 out=gpurun_out/$tag
 mkdir -p $out
