@@ -9,7 +9,7 @@ with tempfile.TemporaryDirectory() as d:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-S",
                            "--cuda-device-only", "-I" + src, "-o", s, os.path.join(src, "jd_kernels.hip")], stderr=subprocess.DEVNULL)
     lines = open(s).read().split("\n")
-a = [i for i, l in enumerate(lines) if l.startswith("_Z12k2_mcu_lanesILi4ELb1EE")][0]
+a = [i for i, l in enumerate(lines) if l.startswith("_Z12k2_mcu_lanesILi4ELb1ELb0EE")][0]
 b = [i for i in range(a, len(lines)) if lines[i].startswith(".Lfunc_end")][0]
 cnt = collections.Counter()
 for l in lines[a:b]:
