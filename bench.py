@@ -18,7 +18,7 @@ can then see the GPU busy; `--repeat 1` makes a step one pass).  Workloads (SURV
        per-rank batches of `--batch` (5000: measured 236k / 243k / 244k / 249k / 248k MP/s at 1000 / 2000 / 2500 / 5000 /
        10000 per batch on one GPU -- fewer, larger launches); strong scaling
   prog the reference's four progressive (SOF2) files and the 14 libjpeg twins through jd_decode_scans_batch (SURVEY
-       row N4), host memory in and out, at batch sizes 1 / 64 / 1024; one rank
+       row N4), host memory in and out, at batch sizes 1 / 64 / 1024 / 4096; one rank
 
 With no `--workload` the headline is c3 and the same process then measures c4 and c5 (and, on one GPU, prog; on several,
 c3 band-sharded) and attaches them as `"workloads": {...}`, each with its own value / ms_per_step / roofline / verified.
@@ -517,7 +517,7 @@ def run_pipeline(jd, R, wl, args):
 def run_progressive(jd, R, args):
     """SURVEY row N4 measured like the others: the reference's four progressive files + the 14 libjpeg twins through
     jd_decode_scans_batch (host memory in, host memory out: parse, table packing, upload, kp_scan levels, K2, download),
-    at batch sizes 1 / 64 / 1024, with the CPU oracle on the same files beside it."""
+    at batch sizes 1 / 64 / 1024 / 4096, with the CPU oracle on the same files beside it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     gold = os.path.join(ROOT, "tests", "golden")
@@ -528,7 +528,7 @@ def run_progressive(jd, R, args):
         return {"dry": True, "files": len(files)} if R.rank == 0 else None
     jd.decode_progressive_batch(files[:2], device=R.gpu)             # warm-up (first launch of kp_scan)
     res, ok = {}, True
-    for nb in (1, 64, 1024):
+    for nb in (1, 64, 1024, 4096):
         grp = [files[i % len(files)] for i in range(nb)]
         gpx = sum(px[i % len(files)] for i in range(nb))
         reps = 5 if nb == 1 else (2 if nb == 64 else 1)
