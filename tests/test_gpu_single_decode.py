@@ -139,3 +139,25 @@ def test_truncated_and_damaged_streams_report_as_the_two_pass_path_does():
         assert codes[0] == codes[1], codes
     with pytest.raises(jd.JpegHipError):
         jd.decode_jpeg(cut)
+
+
+@pytest.mark.parametrize("cap_percent", [0, 35])
+def test_pinned_pipeline_on_the_single_decode_path(cap_percent):
+    """jd_batch_stage_jpegs / submit / wait with the pictures coming back through the pinned staging: the single-decode
+    path, and its fall-back to the two-pass path when the staging overflows -- the copy-back is enqueued again behind
+    the second run"""
+    env = {"JD_NODRI_FUSED": 2}
+    if cap_percent:
+        env["JD_DEBUG_FUSED_CAP_PERCENT"] = cap_percent
+    ims = [jd.SynthImage(640, 360, 2, 2, 3, quality=85, seed=40 + s, detail=2) for s in range(6)]
+    files = [im.encode(0) for im in ims]
+    fr, _, _ = jd.parse(files[0])
+    cap = max(jd.parse(f)[2] for f in files) + 256
+    with knobs(**env):
+        b = jd.Batch([fr] * 3, [cap] * 3, pinned_io=True)
+    for group in (files[:3], files[3:], files[1:4]):
+        b.stage_jpegs(group, threads=2)
+        b.submit(); b.wait()
+        for i, f in enumerate(group):
+            assert np.array_equal(b.host_rgb(i), orclib.OracleImage(f).rgb), i
+    b.close()
