@@ -206,8 +206,9 @@ def decode_progressive(data, device=0, coefficients=False):
     return out
 
 
-def decode_progressive_batch(files, device=0):
-    """jd_decode_scans_batch: many progressive files in one call.  -> (list of RGB arrays, list of per-image status codes)"""
+def decode_progressive_batch(files, device=0, row_pad=None):
+    """jd_decode_scans_batch: many progressive files in one call.  -> (list of RGB arrays, list of per-image status codes).
+    row_pad[i] extra bytes end every output row of picture i (the padding is returned untouched: the caller's bytes)."""
     _ensure_init()
     n = len(files)
     arrs = [_as_u8(f) for f in files]
@@ -218,12 +219,20 @@ def decode_progressive_batch(files, device=0):
     counts = (_ci * n)(*[p[2] for p in parsed])
     ptrs = (_vp * n)(*[a.ctypes.data for a in arrs])
     lens = (_sz * n)(*[a.size for a in arrs])
-    outs = [np.empty((p[0].height, p[0].width, 3), np.uint8) for p in parsed]
-    optrs = (_vp * n)(*[o.ctypes.data for o in outs])
+    pad = list(row_pad) if row_pad is not None else [0] * n
+    bufs = [np.full((p[0].height, p[0].width * 3 + pad[i]), 0xA5, np.uint8) if pad[i] else
+            np.empty((p[0].height, p[0].width * 3), np.uint8) for i, p in enumerate(parsed)]
+    optrs = (_vp * n)(*[o.ctypes.data for o in bufs])
+    strides = (_sz * n)(*[o.shape[1] for o in bufs]) if row_pad is not None else None
     status = (_ci * n)()
-    rc = _lib().jd_decode_scans_batch(n, frames, scans, counts, ptrs, lens, optrs, None, status, device)
+    rc = _lib().jd_decode_scans_batch(n, frames, scans, counts, ptrs, lens, optrs, strides, status, device)
     if rc != 0 and all(s == 0 for s in status):
         raise JpegHipError(rc, "jd_decode_scans_batch")
+    outs = []
+    for i, (o, p) in enumerate(zip(bufs, parsed)):
+        if pad[i] and not (o[:, p[0].width * 3:] == 0xA5).all():
+            raise AssertionError("jd_decode_scans_batch wrote into the row padding of picture %d" % i)
+        outs.append(o[:, :p[0].width * 3].reshape(p[0].height, p[0].width, 3))
     return outs, list(status)
 
 

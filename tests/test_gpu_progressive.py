@@ -69,3 +69,32 @@ def test_progressive_batch():
         assert status[i] == 0, (i, status[i])
         assert np.array_equal(outs[i], orclib.OracleImage(f).rgb), paths[i]
     assert status[-1] in (0, -8, -9, -10)                       # damaged data: an error, or garbage pixels, never a hang
+
+
+def test_progressive_batch_of_many_files():
+    """A call with enough pictures that the copy-out is shared over several host threads (32 pictures a thread), some
+    with padded output rows (the strided copy), one damaged file in the middle: every good picture equals the
+    oracle's, the padding stays the caller's."""
+    paths = (REF_P + TWINS) * 8
+    paths = paths[:150]
+    want = {p: orclib.OracleImage(open(p, "rb").read()).rgb for p in set(paths)}
+    files = [open(p, "rb").read() for p in paths]
+    fr, scans, n = jd.parse_scans(files[1])
+    bad = bytearray(files[1])
+    s = scans[5]
+    for k in range(s.ecs_off + 100, s.ecs_off + 400):
+        if bad[k] != 0xFF and bad[k - 1] != 0xFF:
+            bad[k] ^= 0x5A
+            if bad[k] == 0xFF:
+                bad[k] = 0x7F
+    mid = len(files) // 2
+    files[mid] = bytes(bad)
+    pad = [(0, 5, 0, 64)[i % 4] for i in range(len(files))]
+    for _ in range(2):                                          # the second call reuses nothing of the first
+        outs, status = jd.decode_progressive_batch(files, row_pad=pad)
+        for i, p in enumerate(paths):
+            if i == mid:
+                assert status[i] in (0, -8, -9, -10)
+                continue
+            assert status[i] == 0, (i, status[i])
+            assert np.array_equal(outs[i], want[p]), (i, p)
