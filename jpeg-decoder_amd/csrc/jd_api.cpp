@@ -265,7 +265,12 @@ struct Arena {
             HIPCHK(hipMalloc(p, bytes));
             owned.push_back(*p);
         }
-        if (poison >= 0 && (poison_only < 0 || poison_only == count)) HIPCHK(hipMemset(*p, poison, bytes));
+        if (poison >= 0 && (poison_only < 0 || poison_only == count)) {
+            // (a device memset may return before it has run, and the batch's streams do not wait for the null stream:
+            // without the wait the fill can land on top of the tables uploaded next)
+            HIPCHK(hipMemset(*p, poison, bytes));
+            HIPCHK(hipStreamSynchronize(nullptr));
+        }
         count++;
         total += bytes;
         return JD_OK;
@@ -862,6 +867,9 @@ int wait_on(jd_batch* b) {
         jdk_launch_k0(a, b->d_pre_k0, b->wg_k0, s);             // restores K0's status bits (idempotent)
         jdk_launch_intervals(a, b->d_pre_iv, b->wg_iv, b->max_w_bytes, b->coef_fmts, s);
         if (b->wg_sync) {
+            // (the spine turns the sync workgroups' totals into prefixes IN PLACE: it may only follow a sync launch, which
+            // writes the totals.  When only the single-decode images needed more rounds, none has run since the last spine.)
+            if (!more) jdk_launch_sync(a, b->d_pre_sync, b->wg_sync, b->max_lut_bytes, 1, 1, 0, s);
             jdk_launch_sync_spine(a, s);
             jdk_launch_write_subseq(a, b->d_pre_wr, b->wg_wr, b->max_w_bytes, b->coef_fmts, s);
             if (b->wg_wr && b->any_uniform) jdk_launch_dc_scan(a, s);

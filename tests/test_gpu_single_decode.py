@@ -161,3 +161,28 @@ def test_pinned_pipeline_on_the_single_decode_path(cap_percent):
         for i, f in enumerate(group):
             assert np.array_equal(b.host_rgb(i), orclib.OracleImage(f).rgb), i
     b.close()
+
+
+def test_two_pass_images_survive_the_single_decode_images_host_loop():
+    """A batch with both kinds of no-DRI image: int16 ones (quality 98, or all components on one table pair) stay on the
+    two-pass path, byte-form ones take the single-decode path.  With no blind rounds only the latter need jd_batch_wait's
+    loop -- and the recomputation after it used to run the two-pass images' spine scan a second time over its own output
+    (it turns totals into prefixes in place): Error! EOF or wrong pictures for them (found by tests/fuzz_batches.py)."""
+    specs = [(640, 360, 2, 2, 3, 98, 0), (640, 360, 2, 2, 3, 85, 0), (8, 200, 1, 1, 3, 100, 0), (1023, 33, 1, 1, 3, 85, jd.SynthImage.SHARED_TABLES),
+             (1920, 33, 2, 1, 3, 60, 0), (17, 9, 2, 2, 3, 100, 0), (250, 200, 1, 2, 3, 90, 0), (64, 64, 1, 1, 1, 99, 0)]
+    ims = [jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=10 + k, detail=2) for k, (w, h, hs, vs, nc, q, _) in enumerate(specs)]
+    files = [im.encode(0, s[6]) for im, s in zip(ims, specs)]
+    parsed = [jd.parse(f) for f in files]
+    want = [orclib.OracleImage(f) for f in files]
+    for rounds in (0, 6):
+        with knobs(JD_NODRI_FUSED=2, JD_DEBUG_FUSED_ROUNDS=rounds):
+            b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
+        for rnd in range(2):
+            for i, (f, p) in enumerate(zip(files, parsed)):
+                b.upload(i, f[p[1]:p[1] + p[2]])
+            b.run(); b.wait()
+            for i in range(len(files)):
+                assert b.status(i) == 0, (rounds, rnd, i, b.status(i))
+                assert np.array_equal(b.coefficients(i), want[i].scan_order_coef()), (rounds, rnd, i)
+                assert np.array_equal(b.download(i), want[i].rgb), (rounds, rnd, i)
+        b.close()
