@@ -46,32 +46,62 @@ while time.time() - t0 < budget:
     if kind == "same": slots = [slots[0][:7] + (0,) + slots[0][8:]] * count
     runs = rng_b.choice([1, 2, 3])
     b = None; frames = None; last_status = []
-    desc = ("seed", bseed, kind, count, runs, {k: v for k, v in os.environ.items() if k.startswith("JD_")})
+    pinned = rng_b.random() < 0.3                               # the pinned-memory pipeline instead of upload / run / download
+    desc = ("seed", bseed, kind, count, runs, "pinned" if pinned else "upload", {k: v for k, v in os.environ.items() if k.startswith("JD_")})
+    r = -1
     try:
         for r in range(runs):
             ims = [jd.SynthImage(s[0], s[1], s[2], s[3], s[4], quality=s[5], seed=rng_b.randrange(1 << 30), detail=s[6]) for s in slots]
             files = [im.encode(s[7], s[8]) for im, s in zip(ims, slots)]
             parsed = [jd.parse(f) for f in files]
+            # one image in some runs is damaged (cut short, or a stretch of its entropy-coded bytes wrecked): it may report
+            # anything, its neighbours must not notice
+            hurt = rng_b.randrange(count) if rng_b.random() < 0.3 else -1
+            if hurt >= 0:
+                fr_, off, ln = parsed[hurt]
+                body = bytearray(files[hurt][off:off + ln])
+                if rng_b.random() < 0.5 and ln > 8:
+                    body = body[:rng_b.randrange(1, ln)]
+                    while body and body[-1] == 0xFF: body.pop()
+                    if not body: body = bytearray(b"\x00")
+                else:
+                    at = rng_b.randrange(ln)
+                    for k in range(at, min(ln, at + rng_b.choice([1, 4, 64]))):
+                        if body[k] != 0xFF and (k == 0 or body[k - 1] != 0xFF):
+                            body[k] ^= rng_b.randrange(1, 255)
+                            if body[k] == 0xFF: body[k] = 0x7F
+                files[hurt] = files[hurt][:off] + bytes(body) + files[hurt][off + ln:]
+                parsed[hurt] = (fr_, off, len(body))
             if b is None:
                 frames = [bytes(p[0]) for p in parsed]
-                b = jd.Batch([p[0] for p in parsed], [int(1.3 * p[2]) + 64 for p in parsed], keep_coef=True)
+                b = jd.Batch([p[0] for p in parsed], [int(1.3 * jd.parse(im.encode(s[7], s[8]))[2]) + 64 for im, s in zip(ims, slots)],
+                             keep_coef=True, pinned_io=pinned)
             elif frames != [bytes(p[0]) for p in parsed]:
                 break                                             # (tables that depend on the content: a new batch's business)
-            for i, (f, p) in enumerate(zip(files, parsed)):
-                b.upload(i, f[p[1]:p[1] + p[2]])
-            b.run()
-            try: b.wait()
+            try:
+                if pinned:
+                    for i, (f, p) in enumerate(zip(files, parsed)):
+                        b.stage_ecs(i, f[p[1]:p[1] + p[2]])
+                    b.submit()
+                else:
+                    for i, (f, p) in enumerate(zip(files, parsed)):
+                        b.upload(i, f[p[1]:p[1] + p[2]])
+                    b.run()
+                b.wait()
+            except jd.JpegHipError:
+                if hurt < 0: raise
             finally: last_status = [b.status(i) for i in range(count)]
             look = set(rng_b.sample(range(count), min(count, 3)))
             for i in range(count):
+                if i == hurt: continue
                 ok = b.status(i) == 0 and np.array_equal(b.coefficients(i), ims[i].coefficients())
                 if ok and i in look:
-                    ok = np.array_equal(b.download(i), orclib.OracleImage(ims[i].encode(0, slots[i][8])).rgb)
+                    ok = np.array_equal(b.host_rgb(i) if pinned else b.download(i), orclib.OracleImage(ims[i].encode(0, slots[i][8])).rgb)
                 n_img += 1
                 if not ok:
-                    bad += 1; print("MISMATCH batch", n, "run", r, "image", i, "status", b.status(i), slots[i], desc, flush=True)
+                    bad += 1; print("MISMATCH batch", n, "run", r, "image", i, "status", b.status(i), "damaged:", hurt, slots[i], desc, flush=True)
     except Exception as e:
-        bad += 1; print("EXC", e, desc, flush=True)
+        bad += 1; print("EXC", repr(e), desc, flush=True)
         print("    run", r, "images with a status:", [(i, st, slots[i]) for i, st in enumerate(last_status) if st], flush=True)
     if b is not None: b.close()
     n += 1
