@@ -3,7 +3,7 @@ jd_batch, run two or three times with other content in the same slots (what a ru
 lists, chunk tables, guesses, checkpoints), on either no-DRI path and with the debug knobs that shrink the staging.
 Expected coefficients are the generator's, expected pixels the oracle's (a sample per run: the oracle is the slow side).
 usage: python tests/fuzz_batches.py SEED SECONDS"""
-import os, sys, random, time
+import os, re, sys, random, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import jpeg_decoder_amd as jd, orclib
@@ -15,6 +15,15 @@ modes = [(1, 1, 1), (1, 1, 3), (2, 1, 3), (1, 2, 3), (2, 2, 3)]
 KNOBS = (("JD_NODRI_FUSED", [None, 2, 2, 2, 0]), ("JD_DEBUG_FUSED_ROUNDS", [None, None, 0, 1, 2]),
          ("JD_DEBUG_FUSED_CH0", [None, None, 4, 8, 24]), ("JD_DEBUG_FUSED_CAP_PERCENT", [None, None, None, 30, 60]),
          ("JD_DEBUG_FUSED_LONG_FROM", [None, 0, 0]), ("JD_COEF_FORM", [None, None, 8, 16]), ("JD_DEBUG_POISON", [None, 0, 165, 255]))
+
+
+def unstuff(ecs):
+    """the reference's `_bitstream` (main.go:993-1021) and where the restart markers were (the encoder writes no fill bytes)"""
+    out, rst = bytearray(), []
+    for k, piece in enumerate(re.split(rb"\xff[\xd0-\xd7]", ecs)):
+        if k: rst.append(len(out))
+        out += piece.replace(b"\xff\x00", b"\xff")
+    return bytes(out), rst
 
 
 def slot(rng_):
@@ -47,7 +56,8 @@ while time.time() - t0 < budget:
     runs = rng_b.choice([1, 2, 3])
     b = None; frames = None; last_status = []
     pinned = rng_b.random() < 0.3                               # the pinned-memory pipeline instead of upload / run / download
-    desc = ("seed", bseed, kind, count, runs, "pinned" if pinned else "upload", {k: v for k, v in os.environ.items() if k.startswith("JD_")})
+    pre_unstuffed = not pinned and rng_b.random() < 0.4
+    desc = ("seed", bseed, kind, count, runs, "pinned" if pinned else "upload+unstuffed" if pre_unstuffed else "upload", {k: v for k, v in os.environ.items() if k.startswith("JD_")})
     r = -1
     try:
         for r in range(runs):
@@ -85,7 +95,10 @@ while time.time() - t0 < budget:
                     b.submit()
                 else:
                     for i, (f, p) in enumerate(zip(files, parsed)):
-                        b.upload(i, f[p[1]:p[1] + p[2]])
+                        if pre_unstuffed and i != hurt and rng_b.random() < 0.5:   # the other entry form, per image and per run
+                            bs, rst = unstuff(f[p[1]:p[1] + p[2]])
+                            b.upload_unstuffed(i, bs, rst)
+                        else: b.upload(i, f[p[1]:p[1] + p[2]])
                     b.run()
                 b.wait()
             except jd.JpegHipError:
