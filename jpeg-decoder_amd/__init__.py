@@ -480,7 +480,7 @@ class SynthImage:
         self.width, self.height = width, height
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _syn is not None:       # (module globals are gone at interpreter shutdown)
             _syn().jds_destroy(self._h)
             self._h = None
 
