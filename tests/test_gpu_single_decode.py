@@ -186,3 +186,43 @@ def test_two_pass_images_survive_the_single_decode_images_host_loop():
                 assert np.array_equal(b.coefficients(i), want[i].scan_order_coef()), (rounds, rnd, i)
                 assert np.array_equal(b.download(i), want[i].rgb), (rounds, rnd, i)
         b.close()
+
+
+@pytest.mark.parametrize("rounds", [None, 0])
+def test_mixed_batch_at_the_size_where_the_rule_takes_the_path(rounds):
+    """default path choice: 96 1080p images (the rule's 250,000 sub-sequences) plus the other kinds in the same batch -- int16
+    form (quality 98), one table pair for all components, tiny frames, restart markers, grey; with the blind rounds the
+    library plans, and with none (every single-decode image then waits for jd_batch_wait's loop, the others must not care)."""
+    big = [jd.SynthImage(1920, 1080, 2, 2, 3, quality=92, seed=300 + k, detail=3) for k in range(3)]
+    extra = [((640, 360, 2, 2, 3, 98, 2), 0, 0), ((1023, 200, 1, 1, 3, 85, 2), 0, jd.SynthImage.SHARED_TABLES), ((8, 8, 2, 2, 3, 85, 1), 0, 0),
+             ((17, 200, 2, 1, 3, 100, 1), 0, 0), ((640, 360, 2, 2, 3, 85, 2), 8, 0), ((801, 601, 1, 1, 1, 90, 2), 0, 0), ((250, 9, 1, 2, 3, 60, 3), 0, 0)]
+    ims = [big[k % 3] for k in range(96)]
+    enc = [(0, 0)] * 96
+    for k, (g, ri, fl) in enumerate(extra):
+        at = 5 + 13 * k
+        ims.insert(at, jd.SynthImage(g[0], g[1], g[2], g[3], g[4], quality=g[5], seed=400 + k, detail=g[6])); enc.insert(at, (ri, fl))
+    cache = {}
+    def file_of(i):
+        key = (id(ims[i]), enc[i])
+        if key not in cache: cache[key] = ims[i].encode(*enc[i])
+        return cache[key]
+    files = [file_of(i) for i in range(len(ims))]
+    parsed = [jd.parse(f) for f in files]
+    assert sum((p[2] * 8 + 4095) // 4096 for p in parsed[:5]) * 19 >= 250000
+    with knobs(**({} if rounds is None else {"JD_DEBUG_FUSED_ROUNDS": rounds})):
+        b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
+    for i, (f, p) in enumerate(zip(files, parsed)):
+        b.upload(i, f[p[1]:p[1] + p[2]])
+    b.run(); b.wait()
+    coef, rgb = {}, {}
+    for i in range(len(ims)):
+        key = (id(ims[i]), enc[i])
+        assert b.status(i) == 0, (i, b.status(i))
+        if i < 40 or key not in coef:
+            if key not in coef: coef[key] = ims[i].coefficients()
+            assert np.array_equal(b.coefficients(i), coef[key]), i
+        if key not in rgb:
+            rgb[key] = orclib.OracleImage(ims[i].encode(0, enc[i][1])).rgb
+            assert np.array_equal(b.download(i), rgb[key]), i
+    assert np.array_equal(b.download(len(ims) - 1), rgb[(id(ims[-1]), enc[-1])])
+    b.close()
