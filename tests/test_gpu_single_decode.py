@@ -226,3 +226,29 @@ def test_mixed_batch_at_the_size_where_the_rule_takes_the_path(rounds):
             assert np.array_equal(b.download(i), rgb[key]), i
     assert np.array_equal(b.download(len(ims) - 1), rgb[(id(ims[-1]), enc[-1])])
     b.close()
+
+
+@pytest.mark.parametrize("long_from", [1, 0])
+def test_a_large_image_among_small_ones(long_from):
+    """one image with more than 8192 sub-sequences switches the whole batch to the tiled prefix scan (two launches on the
+    first decode's grid); the small images, the two-pass ones and the DRI one in the same batch go through it too"""
+    specs = [(250, 200, 2, 2, 3, 85, 0, 0), (4096, 4096, 2, 2, 3, 95, 0, 0), (8, 8, 1, 1, 1, 85, 0, 0), (1023, 360, 1, 1, 3, 98, 0, 0),
+             (640, 360, 2, 1, 3, 90, 0, jd.SynthImage.SHARED_TABLES), (1920, 1080, 2, 2, 3, 85, 0, 0), (333, 129, 1, 2, 3, 85, 5, 0), (17, 777, 2, 2, 3, 60, 0, 0)]
+    ims = [jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=500 + k, detail=3) for k, (w, h, hs, vs, nc, q, _, _) in enumerate(specs)]
+    files = [im.encode(s[6], s[7]) for im, s in zip(ims, specs)]
+    parsed = [jd.parse(f) for f in files]
+    assert (parsed[1][2] * 8 + 8191) // 8192 > 8192, parsed[1][2]
+    for rounds in (None, 0):
+        kn = {"JD_NODRI_FUSED": 2, "JD_DEBUG_FUSED_LONG_FROM": long_from}
+        if rounds is not None: kn["JD_DEBUG_FUSED_ROUNDS"] = rounds
+        with knobs(**kn):
+            b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
+        for i, (f, p) in enumerate(zip(files, parsed)):
+            b.upload(i, f[p[1]:p[1] + p[2]])
+        b.run(); b.wait()
+        for i, im in enumerate(ims):
+            assert b.status(i) == 0, (rounds, i, b.status(i))
+            assert np.array_equal(b.coefficients(i), im.coefficients()), (rounds, i)
+            if rounds is None:
+                assert np.array_equal(b.download(i), orclib.OracleImage(im.encode(0, specs[i][7])).rgb), (rounds, i)
+        b.close()
