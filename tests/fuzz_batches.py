@@ -36,6 +36,20 @@ def slot(rng_):
     return (w, h, hs, vs, nc, q, detail, min(ri, 65535), flags)
 
 
+BIG = os.environ.get("FUZZ_BIG")                          # batches large enough for the size rule to take the single-decode path
+_pool = {}
+
+
+def make_image(s, rng_):
+    """a SynthImage for slot s; the large ones come from a small pool (making one costs more than decoding a batch)"""
+    if s[0] * s[1] < 1000000:
+        return jd.SynthImage(s[0], s[1], s[2], s[3], s[4], quality=s[5], seed=rng_.randrange(1 << 30), detail=s[6])
+    key = (s[:7], rng_.randrange(3))
+    if key not in _pool:
+        _pool[key] = jd.SynthImage(s[0], s[1], s[2], s[3], s[4], quality=s[5], seed=1000 + len(_pool), detail=s[6])
+    return _pool[key]
+
+
 only = os.environ.get("FUZZ_BATCH_SEED")                # replay one batch: every draw of a batch comes from its own seed
 while time.time() - t0 < budget:
     bseed = int(only) if only else rng.randrange(1 << 62)
@@ -51,6 +65,11 @@ while time.time() - t0 < budget:
     kind = rng_b.choice(["mixed", "mixed", "nodri", "same"])
     count = rng_b.choice([1, 2, 3, 5, 9, 17, 40])
     slots = [slot(rng_b) for _ in range(count)]
+    if BIG:
+        for k in ("JD_NODRI_FUSED", "JD_DEBUG_FUSED_CH0", "JD_DEBUG_FUSED_CAP_PERCENT", "JD_DEBUG_FUSED_LONG_FROM", "JD_COEF_FORM"): os.environ.pop(k, None)
+        kind = "mixed"; count = rng_b.choice([100, 120, 140])
+        bigs = [(1920, 1080, 2, 2, 3, q, 3, 0, 0) for q in (85, 90, 92)] + [(1920, 1080, 2, 1, 3, 90, 3, 0, 0)]
+        slots = [rng_b.choice(bigs) if rng_b.random() < 0.8 else slot(rng_b) for _ in range(count)]
     if kind == "nodri": slots = [s[:7] + (0,) + s[8:] for s in slots]
     if kind == "same": slots = [slots[0][:7] + (0,) + slots[0][8:]] * count
     runs = rng_b.choice([1, 2, 3])
@@ -61,8 +80,9 @@ while time.time() - t0 < budget:
     r = -1
     try:
         for r in range(runs):
-            ims = [jd.SynthImage(s[0], s[1], s[2], s[3], s[4], quality=s[5], seed=rng_b.randrange(1 << 30), detail=s[6]) for s in slots]
-            files = [im.encode(s[7], s[8]) for im, s in zip(ims, slots)]
+            ims = [make_image(s, rng_b) for s in slots]
+            enc = {}
+            files = [enc.setdefault((id(im), s[7], s[8]), im.encode(s[7], s[8])) for im, s in zip(ims, slots)]
             parsed = [jd.parse(f) for f in files]
             # one image in some runs is damaged (cut short, or a stretch of its entropy-coded bytes wrecked): it may report
             # anything, its neighbours must not notice
@@ -84,7 +104,7 @@ while time.time() - t0 < budget:
                 parsed[hurt] = (fr_, off, len(body))
             if b is None:
                 frames = [bytes(p[0]) for p in parsed]
-                b = jd.Batch([p[0] for p in parsed], [int(1.3 * jd.parse(im.encode(s[7], s[8]))[2]) + 64 for im, s in zip(ims, slots)],
+                b = jd.Batch([p[0] for p in parsed], [int(1.3 * jd.parse(enc[(id(im), s[7], s[8])])[2]) + 64 for im, s in zip(ims, slots)],
                              keep_coef=True, pinned_io=pinned)
             elif frames != [bytes(p[0]) for p in parsed]:
                 break                                             # (tables that depend on the content: a new batch's business)
@@ -107,6 +127,7 @@ while time.time() - t0 < budget:
             look = set(rng_b.sample(range(count), min(count, 3)))
             for i in range(count):
                 if i == hurt: continue
+                if BIG and i not in look and rng_b.random() < 0.8: continue      # (reading 140 big pictures back takes longer than decoding them)
                 ok = b.status(i) == 0 and np.array_equal(b.coefficients(i), ims[i].coefficients())
                 if ok and i in look:
                     ok = np.array_equal(b.host_rgb(i) if pinned else b.download(i), orclib.OracleImage(ims[i].encode(0, slots[i][8])).rgb)
