@@ -252,3 +252,31 @@ def test_a_large_image_among_small_ones(long_from):
             if rounds is None:
                 assert np.array_equal(b.download(i), orclib.OracleImage(im.encode(0, specs[i][7])).rgb), (rounds, i)
         b.close()
+
+
+def test_one_batch_changes_path_from_run_to_run():
+    """the path is chosen per RUN: the same batch of 96 1080p slots decodes short streams (187,000 sub-sequences: two-pass
+    path), then long ones (285,000: single-decode path, which lays the coefficient region out differently), then short
+    ones again"""
+    small = jd.SynthImage(1920, 1080, 2, 2, 3, quality=92, seed=5, detail=1)
+    large = jd.SynthImage(1920, 1080, 2, 2, 3, quality=92, seed=6, detail=3)
+    fs, fl = small.encode(0), large.encode(0)
+    ps, pl = jd.parse(fs), jd.parse(fl)
+    assert bytes(ps[0]) == bytes(pl[0])
+    n = 96
+    assert n * ((ps[2] * 8 + 4095) // 4096) < 250000 <= n * ((pl[2] * 8 + 4095) // 4096)
+    want = {0: (small.coefficients(), orclib.OracleImage(fs).rgb), 1: (large.coefficients(), orclib.OracleImage(fl).rgb)}
+    b = jd.Batch([ps[0]] * n, [pl[2] + 64] * n, keep_coef=True)
+    for rnd, which in enumerate((0, 1, 0, 1)):
+        f, p = (fs, ps) if which == 0 else (fl, pl)
+        for i in range(n):
+            # (the last run mixes the two kinds; its total stays above the rule's threshold)
+            g, q, w = (fs, ps, 0) if (rnd == 3 and i % 8 == 0) else (f, p, which)
+            b.upload(i, g[q[1]:q[1] + q[2]])
+        b.run(); b.wait()
+        for i in (0, 1, 47, 88, n - 1):
+            w = 0 if (rnd == 3 and i % 8 == 0) else which
+            assert b.status(i) == 0
+            assert np.array_equal(b.coefficients(i), want[w][0]), (rnd, i)
+            assert np.array_equal(b.download(i), want[w][1]), (rnd, i)
+    b.close()
