@@ -490,10 +490,10 @@ class SynthImage:
         S.jds_coefficients(self._h, out.ctypes.data)
         return out
 
-    SHARED_TABLES, ZERO_BASED_IDS, DQT_16BIT = 1, 2, 4
+    SHARED_TABLES, ZERO_BASED_IDS, DQT_16BIT, RANDOM_TABLES = 1, 2, 4, 8   # RANDOM_TABLES | (seed << 8)
 
     def encode(self, restart_interval=0, flags=0):
-        """flags: SHARED_TABLES (all components on Huffman tables 0/0), ZERO_BASED_IDS, DQT_16BIT (jd_synth.h)"""
+        """flags: SHARED_TABLES (all components on Huffman tables 0/0), ZERO_BASED_IDS, DQT_16BIT, RANDOM_TABLES | seed << 8 (jd_synth.h)"""
         p, n = ctypes.POINTER(_u8)(), _sz()
         rc = _syn().jds_encode_ex(self._h, restart_interval, flags, ctypes.byref(p), ctypes.byref(n))
         if rc:

@@ -286,6 +286,38 @@ static void put_dht(bitw* w, int tc_th, const uint8_t* bits, const uint8_t* vals
     for (int i = 0; i < nvals; i++) bw_byte(w, vals[i]);
 }
 
+/* JDS_RANDOM_TABLES: a random valid Huffman table over the symbol set `syms` -- a random full binary tree grown leaf by
+ * leaf (half of the splits go to a deepest leaf, so codes of up to 16 bits are common), one deepest leaf left unused
+ * (T.81 C.2: no code of all ones), the symbols dealt over the leaves in random order.  What the decoders' table
+ * packers see of it: primary / secondary splits at every length, pair entries, shortest codes of 1 bit. */
+static uint64_t tab_rnd(uint64_t* st) {
+    uint64_t z = (*st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static void random_table(uint64_t seed, const uint8_t* syms, int nsym, uint8_t bits[16], uint8_t* vals) {
+    uint64_t st = seed;
+    int depth[260], n = 1;
+    depth[0] = 0;
+    while (n < nsym + 1) {
+        int pick = -1;
+        if (tab_rnd(&st) & 1) {                                   /* a deepest leaf that may still be split */
+            for (int i = 0; i < n; i++) if (depth[i] < 16 && (pick < 0 || depth[i] > depth[pick])) pick = i;
+        } else {
+            for (int tries = 0; tries < 64 && pick < 0; tries++) { int i = (int)(tab_rnd(&st) % (uint64_t)n); if (depth[i] < 16) pick = i; }
+        }
+        if (pick < 0) for (int i = 0; i < n; i++) if (depth[i] < 16 && (pick < 0 || depth[i] < depth[pick])) pick = i;
+        depth[pick]++; depth[n++] = depth[pick];
+    }
+    int deepest = 0;
+    for (int i = 1; i < n; i++) if (depth[i] > depth[deepest]) deepest = i;
+    depth[deepest] = depth[n - 1]; n--;                           /* the unused leaf: canonical order puts all ones there */
+    memset(bits, 0, 16);
+    for (int i = 0; i < n; i++) bits[depth[i] - 1]++;
+    for (int i = 0; i < nsym; i++) vals[i] = syms[i];
+    for (int i = nsym - 1; i > 0; i--) { int j = (int)(tab_rnd(&st) % (uint64_t)(i + 1)); uint8_t t = vals[i]; vals[i] = vals[j]; vals[j] = t; }
+}
+
 int jds_encode(const jds_image* im, int restart_interval, uint8_t** out, size_t* out_len) {
     return jds_encode_ex(im, restart_interval, 0, out, out_len);
 }
@@ -297,8 +329,16 @@ int jds_encode_ex(const jds_image* im, int restart_interval, unsigned flags, uin
     if (restart_interval < 0 || restart_interval > 65535) return -1;
     bitw w; memset(&w, 0, sizeof w);
     enc_table dcl, dcc, acl, acc_;
-    build_enc(DC_LUM_BITS, DC_VALS, &dcl); build_enc(DC_CHR_BITS, DC_VALS, &dcc);
-    build_enc(AC_LUM_BITS, AC_LUM_VALS, &acl); build_enc(AC_CHR_BITS, AC_CHR_VALS, &acc_);
+    uint8_t tb[4][16], tv[4][162];                              /* DC luma, AC luma, DC chroma, AC chroma as they go into the file */
+    memcpy(tb[0], DC_LUM_BITS, 16); memcpy(tv[0], DC_VALS, 12); memcpy(tb[1], AC_LUM_BITS, 16); memcpy(tv[1], AC_LUM_VALS, 162);
+    memcpy(tb[2], DC_CHR_BITS, 16); memcpy(tv[2], DC_VALS, 12); memcpy(tb[3], AC_CHR_BITS, 16); memcpy(tv[3], AC_CHR_VALS, 162);
+    if (flags & JDS_RANDOM_TABLES) {
+        const uint64_t ts = (uint64_t)(flags >> 8) * 4u + 1u;
+        random_table(ts, DC_VALS, 12, tb[0], tv[0]); random_table(ts + 1, AC_LUM_VALS, 162, tb[1], tv[1]);
+        random_table(ts + 2, DC_VALS, 12, tb[2], tv[2]); random_table(ts + 3, AC_LUM_VALS, 162, tb[3], tv[3]);
+    }
+    build_enc(tb[0], tv[0], &dcl); build_enc(tb[2], tv[2], &dcc);
+    build_enc(tb[1], tv[1], &acl); build_enc(tb[3], tv[3], &acc_);
     /* SOI, APP0/JFIF */
     bw_u16(&w, 0xFFD8);
     bw_u16(&w, 0xFFE0); bw_u16(&w, 16);
@@ -323,9 +363,9 @@ int jds_encode_ex(const jds_image* im, int restart_interval, unsigned flags, uin
     int ntab = (im->ncomp == 1 || shared) ? 2 : 4;
     bw_u16(&w, 0xFFC4);
     bw_u16(&w, (unsigned)(2 + (17 + 12) + (17 + 162) + (ntab == 4 ? (17 + 12) + (17 + 162) : 0)));
-    put_dht(&w, 0x00, DC_LUM_BITS, DC_VALS, 12);
-    put_dht(&w, 0x10, AC_LUM_BITS, AC_LUM_VALS, 162);
-    if (ntab == 4) { put_dht(&w, 0x01, DC_CHR_BITS, DC_VALS, 12); put_dht(&w, 0x11, AC_CHR_BITS, AC_CHR_VALS, 162); }
+    put_dht(&w, 0x00, tb[0], tv[0], 12);
+    put_dht(&w, 0x10, tb[1], tv[1], 162);
+    if (ntab == 4) { put_dht(&w, 0x01, tb[2], tv[2], 12); put_dht(&w, 0x11, tb[3], tv[3], 162); }
     if (restart_interval > 0) { bw_u16(&w, 0xFFDD); bw_u16(&w, 4); bw_u16(&w, (unsigned)restart_interval); }
     /* SOS */
     bw_u16(&w, 0xFFDA); bw_u16(&w, (unsigned)(6 + 2 * im->ncomp)); bw_byte(&w, (uint8_t)im->ncomp);

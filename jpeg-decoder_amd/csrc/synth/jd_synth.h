@@ -24,8 +24,10 @@ int jds_encode(const jds_image*, int restart_interval, uint8_t** out, size_t* ou
 /* Variants of the file layout for the parser / decoder corner cases (same coefficients):
  *   JDS_SHARED_TABLES   every component codes through Huffman tables 0/0 (one DC + one AC table in the file)
  *   JDS_ZERO_BASED_IDS  component ids 0,1,2 instead of 1,2,3 (main.go:133-135, 153-157, 961-963)
- *   JDS_DQT_16BIT       16-bit DQT entries with a non-zero high byte, which the reference drops (main.go:60-68) */
-enum { JDS_SHARED_TABLES = 1u, JDS_ZERO_BASED_IDS = 2u, JDS_DQT_16BIT = 4u };
+ *   JDS_DQT_16BIT       16-bit DQT entries with a non-zero high byte, which the reference drops (main.go:60-68)
+ *   JDS_RANDOM_TABLES   random valid Huffman tables instead of Annex K.3's (code lengths 1..16, symbols in random
+ *                       order); flags >> 8 seeds them */
+enum { JDS_SHARED_TABLES = 1u, JDS_ZERO_BASED_IDS = 2u, JDS_DQT_16BIT = 4u, JDS_RANDOM_TABLES = 8u };
 int jds_encode_ex(const jds_image*, int restart_interval, unsigned flags, uint8_t** out, size_t* out_len);
 void jds_free_buffer(uint8_t*);
 #ifdef __cplusplus

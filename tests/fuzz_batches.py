@@ -33,6 +33,7 @@ def slot(rng_):
     mcus = ((w + 8 * hs - 1) // (8 * hs)) * ((h + 8 * vs - 1) // (8 * vs))
     ri = rng_.choice([0, 0, 0, 0, 1, 3, 8, max(1, mcus // 3)])
     flags = rng_.choice([0, 0, 0, jd.SynthImage.SHARED_TABLES])
+    if rng_.random() < 0.3: flags |= jd.SynthImage.RANDOM_TABLES | (rng_.randrange(1 << 20) << 8)   # random valid Huffman tables, codes of 1..16 bits
     return (w, h, hs, vs, nc, q, detail, min(ri, 65535), flags)
 
 

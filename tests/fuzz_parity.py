@@ -25,6 +25,7 @@ while time.time() - t0 < budget:
             else: os.environ[k] = str(v)
     form = rng.choice([None, 8, 16])
     flags = rng.choice([0, 0, 0, jd.SynthImage.SHARED_TABLES])
+    if rng.random() < 0.35: flags |= jd.SynthImage.RANDOM_TABLES | (rng.randrange(1 << 20) << 8)   # random valid Huffman tables, codes of 1..16 bits
     seed = rng.randrange(1 << 30)
     im = jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=seed, detail=detail)
     data, twin = im.encode(ri, flags), im.encode(0, flags)
