@@ -216,3 +216,31 @@ def test_chroma_samples_beyond_int16_are_flagged(form):
         data = _colour444_jpeg(ok, 255)
         assert np.array_equal(jd.decode_jpeg(data), orclib.OracleImage(data).rgb)
         _expect(_colour444_jpeg(bad, 255), -9)
+
+
+@pytest.mark.parametrize("w,h,hs,vs,nc", [(65535, 16, 2, 2, 3), (16, 65535, 2, 2, 3), (65535, 9, 1, 1, 1), (9, 65535, 1, 2, 3), (65535, 8, 2, 1, 3)])
+def test_largest_dimensions(w, h, hs, vs, nc):
+    """the 16-bit limits of SOF0's width and height (main.go:117-118), one at a time: a row of 8192 MCUs, a column of 8192;
+    with restart markers every MCU row, with none on either path"""
+    im = jd.SynthImage(w, h, hs, vs, nc, quality=85, seed=w % 97 + h % 89, detail=2)
+    want = orclib.OracleImage(im.encode(0)).rgb
+    mcux = (w + 8 * hs - 1) // (8 * hs)
+    for ri, fused in ((0, None), (0, 2), (0, 0), (mcux, None), (7, None)):
+        old = os.environ.get("JD_NODRI_FUSED")
+        try:
+            if fused is None: os.environ.pop("JD_NODRI_FUSED", None)
+            else: os.environ["JD_NODRI_FUSED"] = str(fused)
+            data = im.encode(ri)
+            assert np.array_equal(jd.decode_coefficients(data), im.coefficients()), (ri, fused)
+            assert np.array_equal(jd.decode_jpeg(data), want), (ri, fused)
+        finally:
+            if old is None: os.environ.pop("JD_NODRI_FUSED", None)
+            else: os.environ["JD_NODRI_FUSED"] = old
+
+
+def test_largest_restart_interval():
+    """DRI = 65535 (the field's limit) on a frame of 82,944 MCUs: two intervals, the second one short"""
+    im = jd.SynthImage(2304, 2304, 1, 1, 3, quality=60, seed=3, detail=1)
+    data = im.encode(65535)
+    assert np.array_equal(jd.decode_coefficients(data), im.coefficients())
+    assert np.array_equal(jd.decode_jpeg(data), orclib.OracleImage(im.encode(0)).rgb)
