@@ -33,7 +33,8 @@ void jdk_launch_sync_spine(const JdKernelArgs& a, hipStream_t s);
 void jdk_launch_write_subseq(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, uint32_t fmts, hipStream_t s);
 void jdk_launch_coef8_expand(const JdKernelArgs& a, int img, uint32_t nblocks, int16_t* d_out, hipStream_t s);
 void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, hipStream_t s);
-void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, uint32_t lanes0, hipStream_t s);
+void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, uint32_t lanes0,
+                       uint32_t share, uint32_t share_w_off, uint32_t share_w_len, hipStream_t s);
 void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s);
 void jdk_launch_fscan_index(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int tiled, hipStream_t s);
 void jdk_launch_dc_scan(const JdKernelArgs& a, hipStream_t s);
@@ -301,6 +302,7 @@ struct jd_batch {
     int fscan_tiled = 0;                        // some image has more than 8192 sub-sequences: prefix scan in tiles
     uint32_t fsub_bits = JD_SUBSEQ_BITS;        // sub-sequence size of the single-decode path in this run (by the batch's size)
     uint32_t redo0_lanes = JD_F_REDO_LANES;     // workgroup size of the first re-decode round (by the images' list lengths)
+    uint32_t f_share = 0, f_share_off = 0, f_share_len = 0;   // re-decode launches of a batch on one table set: eight waves per copy of the tables (refresh; bit 0: round 0, bit 1: later rounds)
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
     bool fused_always = false;                 // JD_NODRI_FUSED=2: whatever the batch's size (tests)
     std::vector<uint8_t> fz_ok;                // per image: planned for the single-decode path (staging allocated)
@@ -427,6 +429,24 @@ int refresh(jd_batch* b, hipStream_t s) {
         for (int i = 0; i < n; i++) if (b->img[i].flags & JD_IMG_FUSED) { subs_f += ((uint64_t)b->img[i].ecs_len * 8 + b->fsub_bits - 1) / b->fsub_bits; nfz2++; }
         const uint64_t est = nfz2 ? subs_f / nfz2 / 12 : 0;
         b->redo0_lanes = est <= 48 ? 64u : est <= 110 ? 128u : JD_F_REDO_LANES;
+        // Many small images on ONE table set (a batch of photographs of one camera setting): the re-decode launches
+        // put eight waves behind one copy of the tables, a wave or two per image (k1f_write, share_w), instead of a
+        // workgroup per image -- twice as many walks run at once.  Not with a long list in the batch: its image's one or
+        // two waves would walk it tile after tile.
+        uint32_t nsub_max = 0; bool one_set = nfz2 > 0; b->f_share_off = b->f_share_len = 0;
+        for (int i = 0; i < n; i++) {
+            const JdImg& im = b->img[i];
+            if (!(im.flags & JD_IMG_FUSED)) continue;
+            nsub_max = std::max<uint32_t>(nsub_max, (uint32_t)(((uint64_t)im.ecs_len * 8 + b->fsub_bits - 1) / b->fsub_bits));
+            if (!b->f_share_len) { b->f_share_off = im.w_off; b->f_share_len = im.w_len; }
+            else if (im.w_off != b->f_share_off || im.w_len != b->f_share_len) one_set = false;
+        }
+        // (bit 0: round 0, whose lists hold a twelfth of an image's sub-sequences; bit 1: the later rounds, a 150th and less)
+        if (env_int("JD_DEBUG_FUSED_SHARE", 1) == 0) one_set = false;
+        // Only where a workgroup per image would not fit the machine at once (eight one-wave workgroups per CU: 2048): with
+        // fewer images the walks are better spread over all CUs (1080p images: 512 - 2 % with sharing, 1024 + 0.5 %, 2048 + 5 %, 5000 + 4 %).
+        const bool many = nfz2 >= (uint64_t)env_int("JD_DEBUG_FUSED_SHARE_FROM", 1200);
+        b->f_share = (one_set && many && b->redo0_lanes <= 128u && nsub_max <= 2048u ? 1u : 0u) | (one_set && many && nsub_max <= 8192u ? 2u : 0u);
     }
     if (b->fused_rounds_env < 0) b->fused_rounds = (uint64_t)b->wg_f * 64 * JD_W_WAVES < 200000 ? 3 : JD_F_ROUNDS;
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc, b->desc_bytes, hipMemcpyHostToDevice, s));
@@ -468,10 +488,10 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
             // the writing decode from the blind guesses, then JD_F_ROUNDS rounds of "list the sub-sequences whose entry is
             // not their predecessor's exit, decode those again" (the first redoes one in twelve, the rest next to nothing),
             // a last check for jd_batch_wait, the prefix scan and the block index
-            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, 0, s);
+            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, 0, 0, 0, 0, s);
             for (int r = 0; r < b->fused_rounds; r++) {
                 jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, r, s);
-                jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, b->redo0_lanes, s);
+                jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, b->redo0_lanes, b->f_share & (r == 0 ? 1u : 2u), b->f_share_off, b->f_share_len, s);
             }
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
             jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, b->fscan_tiled, s);
@@ -853,7 +873,7 @@ int wait_on(jd_batch* b) {
         // single-decode path: the last check left a list; decode it, check again, until a check finds nothing
         guard = 0;
         if (more_f) do {
-            jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, JD_F_ROUNDS, 64, s);
+            jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, JD_F_ROUNDS, 64, b->f_share & 2u, b->f_share_off, b->f_share_len, s);
             HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
             HIPCHK(hipMemsetAsync(b->d_fcount + (size_t)JD_F_ROUNDS * b->n, 0, (size_t)b->n * sizeof(uint32_t), s));
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);

@@ -1581,24 +1581,45 @@ __global__ __launch_bounds__(JD_SYNC_WG, 6) void k1f_cold(JdKernelArgs a) {
     }
 }
 
-__global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, uint32_t lut_bytes, int round) {
-    const int img = find_image(a.prefix, a.n_images, blockIdx.x);
-    const JdImg& im = a.imgs[img];
-    if (!(im.flags & JD_IMG_FUSED)) return;
-    const uint32_t lw = blockIdx.x - a.prefix[img], nwg = a.prefix[img + 1] - a.prefix[img];
-    const uint32_t wg_lanes = blockDim.x;                       // 64 * JD_W_WAVES for the first decode, JD_F_REDO_LANES for the lists
-    const uint32_t slen = a.stream_len[img];
+// share_w = 0: a workgroup serves one image (image-relative workgroup lw of the launch's prefix).
+// share_w = 1, 2, 4 (re-decode rounds of a batch whose single-decode images all use ONE table set, lists of a wave or two):
+// a workgroup of eight waves loads the tables once and every share_w waves of it walk the list of an image of their own
+// -- workgroup g serves images g * 8 / share_w ... .  A list of a handful of entries needs one wave, and one-wave
+// workgroups each with the tables to themselves fit eight to a CU; this way sixteen such walks run on a CU at once.
+__global__ __launch_bounds__(64 * JD_W_WAVES, 4) void k1f_write(JdKernelArgs a, uint32_t lut_bytes, int round, uint32_t share_w,
+                                                                 uint32_t share_w_off, uint32_t share_w_len) {
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int img;
+    uint32_t first_tile, tile_step, tile_lanes, in_tile;
+    if (share_w) {
+        const uint32_t per_wg = (blockDim.x >> 6) / share_w;
+        img = (int)(blockIdx.x * per_wg + wave / share_w);
+        first_tile = wave % share_w; tile_step = share_w; tile_lanes = 64u; in_tile = threadIdx.x & 63u;
+    } else {
+        img = find_image(a.prefix, a.n_images, blockIdx.x);
+        first_tile = blockIdx.x - a.prefix[img]; tile_step = a.prefix[img + 1] - a.prefix[img];
+        tile_lanes = blockDim.x;                                // 64 * JD_W_WAVES for the first decode, 64 .. JD_F_REDO_LANES for the lists
+        in_tile = threadIdx.x;
+    }
+    const bool mine = img < a.n_images && (a.imgs[img < a.n_images ? img : 0].flags & JD_IMG_FUSED) != 0;
+    const JdImg& im = a.imgs[mine ? img : 0];
+    const uint32_t slen = mine ? a.stream_len[img] : 0u;
     const uint32_t sbits = slen * 8u;
     const uint32_t nsub = (sbits + a.fsub_bits - 1u) / a.fsub_bits;
-    const uint32_t n_todo = round < 0 ? nsub : a.fcount[(uint32_t)round * (uint32_t)a.n_images + (uint32_t)img];
-    if (lw * wg_lanes >= n_todo) return;                      // whole workgroup idle (uniform)
-    load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
+    const uint32_t n_todo = !mine ? 0u : round < 0 ? nsub : a.fcount[(uint32_t)round * (uint32_t)a.n_images + (uint32_t)img];
+    if (share_w) {
+        if (!__syncthreads_or(first_tile * tile_lanes < n_todo)) return;   // none of the workgroup's images has a list
+        load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + share_w_off, share_w_len * 2u);
+    } else {
+        if (!mine || first_tile * tile_lanes >= n_todo) return;          // whole workgroup idle (uniform)
+        load_lut(reinterpret_cast<uint16_t*>(dyn_lds), a.lut + im.w_off, im.w_len * 2u);
+    }
     // (a re-decode launch has fewer workgroups than the list may have tiles: each walks its share.  Its workgroups are small:
     // a list is short, and a big workgroup with one busy wave would still hold its whole share of the CU's LDS)
 #pragma unroll 1
-    for (uint32_t tile = lw; tile * wg_lanes < n_todo; tile += nwg) {
-        const uint32_t L = tile * wg_lanes + threadIdx.x;
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * wg_lanes + (threadIdx.x & ~63u))) >= n_todo) continue;   // wave-uniform
+    for (uint32_t tile = first_tile; tile * tile_lanes < n_todo; tile += tile_step) {
+        const uint32_t L = tile * tile_lanes + in_tile;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * tile_lanes + (in_tile & ~63u))) >= n_todo) continue;   // wave-uniform
         FusedSeg fs; fs.valid = L < n_todo; fs.c0 = 0; fs.entry = JD_FSTATE(0u, 0u); fs.old_chunks = 0; fs.gsub = im.subseq_base; fs.slot0 = 0;
         fs.cutoff = round < 0; fs.guess_exit = 0;
         Segment sg; sg.start_bit = 0; sg.end_bit = 0; sg.nblk = 0; sg.blk0 = 0; sg.p0 = sg.p1 = sg.p2 = 0;
@@ -2725,18 +2746,25 @@ void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t 
 }
 // round < 0: every sub-sequence; round >= 0: the sub-sequences k1f_check listed for that round
 // lanes0: workgroup size of round 0 (64 / 128 / JD_F_REDO_LANES, by how long an image's first list will be)
-void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, uint32_t lanes0, hipStream_t s) {
+void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, uint32_t lanes0,
+                       uint32_t share, uint32_t share_w_off, uint32_t share_w_len, hipStream_t s) {
     if (!wgs) return;
     JdKernelArgs x = a; x.prefix = d_prefix;
     const uint32_t lb = (lut_bytes + 127u) & ~127u;
+    if (lb + JD_W_WAVES * JD_WAVE_LDS > 64u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1f_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb + JD_W_WAVES * JD_WAVE_LDS));
     // lanes per workgroup: the first decode fills eight waves; round 0's lists (one sub-sequence in twelve) fill one to
     // four; later lists are a handful of entries per image -- one wave, so that a CU holds eight such workgroups, not
     // three (a workgroup's LDS is the tables + 8 KB per wave, and these launches are bound by how many walks run at once)
     const uint32_t lanes = round < 0 ? 64u * JD_W_WAVES : round == 0 ? lanes0 : 64u;
+    if (share && round >= 0 && lanes <= 256u) {                  // one table set for all: eight waves share it, lanes / 64 waves per image
+        const uint32_t w = lanes / 64u, per_wg = JD_W_WAVES / w;
+        hipLaunchKernelGGL(k1f_write, dim3(((uint32_t)a.n_images + per_wg - 1u) / per_wg), dim3(64u * JD_W_WAVES), lb + JD_W_WAVES * JD_WAVE_LDS, s,
+                           x, lb, round, w, share_w_off, share_w_len);
+        return;
+    }
     const uint32_t lds = lb + (lanes / 64u) * JD_WAVE_LDS;
-    if (lb + JD_W_WAVES * JD_WAVE_LDS > 64u * 1024u)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1f_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb + JD_W_WAVES * JD_WAVE_LDS));
-    hipLaunchKernelGGL(k1f_write, dim3(wgs), dim3(lanes), lds, s, x, lb, round);
+    hipLaunchKernelGGL(k1f_write, dim3(wgs), dim3(lanes), lds, s, x, lb, round, 0u, 0u, 0u);
 }
 void jdk_launch_fcheck(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, int round, hipStream_t s) {
     if (!wgs) return;

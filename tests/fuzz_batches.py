@@ -14,7 +14,8 @@ t0 = time.time(); n = 0; bad = 0; t_say = t0; n_img = 0
 modes = [(1, 1, 1), (1, 1, 3), (2, 1, 3), (1, 2, 3), (2, 2, 3)]
 KNOBS = (("JD_NODRI_FUSED", [None, 2, 2, 2, 0]), ("JD_DEBUG_FUSED_ROUNDS", [None, None, 0, 1, 2]),
          ("JD_DEBUG_FUSED_CH0", [None, None, 4, 8, 24]), ("JD_DEBUG_FUSED_CAP_PERCENT", [None, None, None, 30, 60]),
-         ("JD_DEBUG_FUSED_LONG_FROM", [None, 0, 0]), ("JD_COEF_FORM", [None, None, 8, 16]), ("JD_DEBUG_POISON", [None, 0, 165, 255]))
+         ("JD_DEBUG_FUSED_LONG_FROM", [None, 0, 0]), ("JD_COEF_FORM", [None, None, 8, 16]), ("JD_DEBUG_POISON", [None, 0, 165, 255]),
+         ("JD_DEBUG_FUSED_SHARE_FROM", [None, 1, 1]))           # 1: re-decode launches with eight waves per copy of the tables whatever the batch's size
 
 
 def unstuff(ecs):

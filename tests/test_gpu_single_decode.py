@@ -280,3 +280,30 @@ def test_one_batch_changes_path_from_run_to_run():
             assert np.array_equal(b.coefficients(i), want[w][0]), (rnd, i)
             assert np.array_equal(b.download(i), want[w][1]), (rnd, i)
     b.close()
+
+
+@pytest.mark.parametrize("rounds,long_from", [(None, 0), (None, 1), (0, 0), (1, 1)])
+def test_redecode_launches_that_share_one_copy_of_the_tables(rounds, long_from):
+    """a batch whose single-decode images all use one table set re-decodes with eight waves behind one copy of the tables, a
+    wave or two per image (k1f_write's share_w; the library does so from 1200 images, JD_DEBUG_FUSED_SHARE_FROM=1 here):
+    images with lists of a few entries and of a few tiles, images without any list (one sub-sequence), a DRI image and a
+    two-pass image in between, every round count incl. the host's loop"""
+    specs = [(640, 360, 2, 2, 3, 85, 0), (8, 8, 1, 1, 1, 85, 0), (1920, 1080, 2, 2, 3, 92, 0), (250, 200, 1, 2, 3, 60, 0), (640, 360, 2, 2, 3, 98, 0),
+             (333, 129, 2, 1, 3, 85, 7), (1023, 777, 1, 1, 3, 85, 0), (17, 9, 2, 2, 3, 85, 0), (801, 601, 1, 1, 1, 90, 0)] * 3
+    ims = [jd.SynthImage(w, h, hs, vs, nc, quality=q, seed=700 + k, detail=1 + k % 3) for k, (w, h, hs, vs, nc, q, _) in enumerate(specs)]
+    files = [im.encode(s[6]) for im, s in zip(ims, specs)]
+    parsed = [jd.parse(f) for f in files]
+    kn = {"JD_NODRI_FUSED": 2, "JD_DEBUG_FUSED_SHARE_FROM": 1, "JD_DEBUG_FUSED_LONG_FROM": long_from}
+    if rounds is not None: kn["JD_DEBUG_FUSED_ROUNDS"] = rounds
+    with knobs(**kn):
+        b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
+    for rnd in range(2):
+        for i, (f, p) in enumerate(zip(files, parsed)):
+            b.upload(i, f[p[1]:p[1] + p[2]])
+        b.run(); b.wait()
+        for i, im in enumerate(ims):
+            assert b.status(i) == 0, (rnd, i, b.status(i))
+            assert np.array_equal(b.coefficients(i), im.coefficients()), (rnd, i)
+            if rnd == 0 and i < 9:
+                assert np.array_equal(b.download(i), orclib.OracleImage(im.encode(0)).rgb), (rnd, i)
+    b.close()
