@@ -403,7 +403,7 @@ def run_resident(jd, R, wl, shard, args, headline):
     # ---- the same batches dealt over two streams (extra, one rank: what a host with several batches in flight gets; the
     # figures above stay single-stream so that the stage times add up to the pass) -----------------------------------
     two = None
-    if len(batches) >= 2 and len(tstreams) == 1 and R.world == 1:
+    if len(batches) >= 2 and len(tstreams) == 1 and R.world == 1 and not args.no_two_streams:
         s2 = [torch.cuda.Stream(device=R.dev) for _ in range(2)]
 
         def pass2():
@@ -578,6 +578,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end sample of the default mode")
     ap.add_argument("--no-extra", action="store_true", help="--workload all: measure the headline only")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the two_streams extra (profiles: its overlapping launches would blur the per-kernel figures)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher, rendezvous (gloo) and planning only")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank decodes on device 0, gloo for the barrier "
                                                              "(RCCL refuses two ranks on one device); the value then measures nothing")

@@ -14,9 +14,9 @@ export TMPDIR=/tmp
 for wl in $wls; do
   timeout -k 10 300 python3 bench.py --workload $wl --steps 20 --warmup 5 > $out/bench_$wl.json 2> $out/bench_$wl.err
   echo "bench $wl done"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python3 bench.py --workload $wl --steps 10 --no-cpu-baseline --no-e2e > $out/stats_$wl.json 2> $out/stats_$wl.log
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python3 bench.py --workload $wl --steps 10 --no-cpu-baseline --no-e2e --no-two-streams > $out/stats_$wl.json 2> $out/stats_$wl.log
   echo "stats $wl done"
-  short="--steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --no-e2e"
+  short="--steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --no-e2e --no-two-streams"
   timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$wl -- python3 bench.py --workload $wl $short > $out/pmc_fetch_$wl.json 2> $out/pmc_fetch_$wl.log
   timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$wl -- python3 bench.py --workload $wl $short > $out/pmc_write_$wl.json 2> $out/pmc_write_$wl.log
   echo "pmc $wl done"
