@@ -302,7 +302,7 @@ struct jd_batch {
     int fscan_tiled = 0;                        // some image has more than 8192 sub-sequences: prefix scan in tiles
     uint32_t fsub_bits = JD_SUBSEQ_BITS;        // sub-sequence size of the single-decode path in this run (by the batch's size)
     uint32_t redo0_lanes = JD_F_REDO_LANES;     // workgroup size of the first re-decode round (by the images' list lengths)
-    uint32_t f_share = 0, f_share_off = 0, f_share_len = 0;   // re-decode launches of a batch on one table set: eight waves per copy of the tables (refresh; bit 0: round 0, bit 1: later rounds)
+    uint32_t f_share = 0, f_share_first = 0, f_share_off = 0, f_share_len = 0;   // re-decode launches of a batch on one table set: eight waves per copy of the tables (refresh; bit 0: round 0, bit 1: later rounds)
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
     bool fused_always = false;                 // JD_NODRI_FUSED=2: whatever the batch's size (tests)
     std::vector<uint8_t> fz_ok;                // per image: planned for the single-decode path (staging allocated)
@@ -447,6 +447,9 @@ int refresh(jd_batch* b, hipStream_t s) {
         // fewer images the walks are better spread over all CUs (1080p images: 512 - 2 % with sharing, 1024 + 0.5 %, 2048 + 5 %, 5000 + 4 %).
         const bool many = nfz2 >= (uint64_t)env_int("JD_DEBUG_FUSED_SHARE_FROM", 1200);
         b->f_share = (one_set && many && b->redo0_lanes <= 128u && nsub_max <= 2048u ? 1u : 0u) | (one_set && many && nsub_max <= 8192u ? 2u : 0u);
+        // ... and the FIRST decode of a batch of many tiny images (thumbnails: every image a wave or a few): a 512-lane
+        // workgroup per image holds 78 KB of LDS for its one busy wave -- two images per CU at a time instead of sixteen
+        b->f_share_first = (one_set && many && nsub_max <= 256u) ? (nsub_max <= 64u ? 1u : nsub_max <= 128u ? 2u : 4u) : 0u;
     }
     if (b->fused_rounds_env < 0) b->fused_rounds = (uint64_t)b->wg_f * 64 * JD_W_WAVES < 200000 ? 3 : JD_F_ROUNDS;
     HIPCHK(hipMemcpyAsync(b->d_desc, b->h_desc, b->desc_bytes, hipMemcpyHostToDevice, s));
@@ -488,10 +491,10 @@ int enqueue_stage(jd_batch* b, int stage, hipStream_t s) {
             // the writing decode from the blind guesses, then JD_F_ROUNDS rounds of "list the sub-sequences whose entry is
             // not their predecessor's exit, decode those again" (the first redoes one in twelve, the rest next to nothing),
             // a last check for jd_batch_wait, the prefix scan and the block index
-            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, 0, 0, 0, 0, s);
+            jdk_launch_fwrite(a, b->d_pre_f, b->wg_f, b->max_w_bytes, -1, 0, b->f_share_first, b->f_share_off, b->f_share_len, s);
             for (int r = 0; r < b->fused_rounds; r++) {
                 jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, r, s);
-                jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, b->redo0_lanes, b->f_share & (r == 0 ? 1u : 2u), b->f_share_off, b->f_share_len, s);
+                jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, r, b->redo0_lanes, r == 0 ? ((b->f_share & 1u) ? b->redo0_lanes / 64u : 0u) : (b->f_share >> 1), b->f_share_off, b->f_share_len, s);
             }
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);
             jdk_launch_fscan_index(a, b->d_pre_f, b->wg_f, b->fscan_tiled, s);
@@ -873,7 +876,7 @@ int wait_on(jd_batch* b) {
         // single-decode path: the last check left a list; decode it, check again, until a check finds nothing
         guard = 0;
         if (more_f) do {
-            jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, JD_F_ROUNDS, 64, b->f_share & 2u, b->f_share_off, b->f_share_len, s);
+            jdk_launch_fwrite(a, b->d_pre_fr, b->wg_fr, b->max_w_bytes, JD_F_ROUNDS, 64, b->f_share >> 1, b->f_share_off, b->f_share_len, s);
             HIPCHK(hipMemsetAsync(b->d_changed, 0, 64 * sizeof(uint32_t), s));
             HIPCHK(hipMemsetAsync(b->d_fcount + (size_t)JD_F_ROUNDS * b->n, 0, (size_t)b->n * sizeof(uint32_t), s));
             jdk_launch_fcheck(a, b->d_pre_f, b->wg_f, JD_F_ROUNDS, s);

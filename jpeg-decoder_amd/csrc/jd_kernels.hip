@@ -2746,6 +2746,7 @@ void jdk_launch_fcold(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t 
 }
 // round < 0: every sub-sequence; round >= 0: the sub-sequences k1f_check listed for that round
 // lanes0: workgroup size of round 0 (64 / 128 / JD_F_REDO_LANES, by how long an image's first list will be)
+// share: 0, or the waves an image gets in workgroups of eight waves on one copy of the tables (k1f_write's share_w: 1, 2, 4)
 void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t wgs, uint32_t lut_bytes, int round, uint32_t lanes0,
                        uint32_t share, uint32_t share_w_off, uint32_t share_w_len, hipStream_t s) {
     if (!wgs) return;
@@ -2757,10 +2758,10 @@ void jdk_launch_fwrite(const JdKernelArgs& a, const uint32_t* d_prefix, uint32_t
     // four; later lists are a handful of entries per image -- one wave, so that a CU holds eight such workgroups, not
     // three (a workgroup's LDS is the tables + 8 KB per wave, and these launches are bound by how many walks run at once)
     const uint32_t lanes = round < 0 ? 64u * JD_W_WAVES : round == 0 ? lanes0 : 64u;
-    if (share && round >= 0 && lanes <= 256u) {                  // one table set for all: eight waves share it, lanes / 64 waves per image
-        const uint32_t w = lanes / 64u, per_wg = JD_W_WAVES / w;
+    if (share == 1u || share == 2u || share == 4u) {             // one table set for all: eight waves share it, `share` waves per image
+        const uint32_t per_wg = JD_W_WAVES / share;
         hipLaunchKernelGGL(k1f_write, dim3(((uint32_t)a.n_images + per_wg - 1u) / per_wg), dim3(64u * JD_W_WAVES), lb + JD_W_WAVES * JD_WAVE_LDS, s,
-                           x, lb, round, w, share_w_off, share_w_len);
+                           x, lb, round, share, share_w_off, share_w_len);
         return;
     }
     const uint32_t lds = lb + (lanes / 64u) * JD_WAVE_LDS;

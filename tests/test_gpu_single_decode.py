@@ -307,3 +307,29 @@ def test_redecode_launches_that_share_one_copy_of_the_tables(rounds, long_from):
             if rnd == 0 and i < 9:
                 assert np.array_equal(b.download(i), orclib.OracleImage(im.encode(0)).rgb), (rnd, i)
     b.close()
+
+
+@pytest.mark.parametrize("biggest,rounds", [((160, 120), None), ((320, 240), None), ((640, 360), None), ((320, 240), 0)])
+def test_first_decode_of_many_small_images_on_one_copy_of_the_tables(biggest, rounds):
+    """batches of thumbnails: when no image has more than 256 sub-sequences the FIRST decode, too, runs in workgroups of
+    eight waves on one copy of the tables -- one, two or four waves per image by the largest image (here about 17, 66 and 203
+    sub-sequences) -- instead of a 512-lane workgroup per image (20,000 x 320x240: 61,600 -> 142,500 MP/s)"""
+    sizes = [biggest, (8, 8), (96, 64), (64, 9), biggest, (17, 33), (120, 90), biggest]
+    specs = [(w, h) + m for k, (w, h) in enumerate(sizes * 3) for m in [[(2, 2, 3), (1, 1, 3), (2, 1, 3), (1, 1, 1), (1, 2, 3)][k % 5]]]
+    ims = [jd.SynthImage(w, h, hs, vs, nc, quality=85, seed=900 + k, detail=1 + k % 3) for k, (w, h, hs, vs, nc) in enumerate(specs)]
+    files = [im.encode(0) for im in ims]
+    parsed = [jd.parse(f) for f in files]
+    kn = {"JD_NODRI_FUSED": 2, "JD_DEBUG_FUSED_SHARE_FROM": 1}
+    if rounds is not None: kn["JD_DEBUG_FUSED_ROUNDS"] = rounds
+    with knobs(**kn):
+        b = jd.Batch([p[0] for p in parsed], [p[2] for p in parsed], keep_coef=True)
+    for rnd in range(2):
+        for i, (f, p) in enumerate(zip(files, parsed)):
+            b.upload(i, f[p[1]:p[1] + p[2]])
+        b.run(); b.wait()
+        for i, im in enumerate(ims):
+            assert b.status(i) == 0, (rnd, i, b.status(i))
+            assert np.array_equal(b.coefficients(i), im.coefficients()), (rnd, i)
+            if rnd == 0:
+                assert np.array_equal(b.download(i), orclib.OracleImage(files[i]).rgb), (rnd, i)
+    b.close()
