@@ -302,6 +302,7 @@ struct jd_batch {
     int fscan_tiled = 0;                        // some image has more than 8192 sub-sequences: prefix scan in tiles
     uint32_t fsub_bits = JD_SUBSEQ_BITS;        // sub-sequence size of the single-decode path in this run (by the batch's size)
     uint32_t redo0_lanes = JD_F_REDO_LANES;     // workgroup size of the first re-decode round (by the images' list lengths)
+    bool f_small_class = false;               // this run: many small images on one table set (refresh)
     uint32_t f_share = 0, f_share_first = 0, f_share_off = 0, f_share_len = 0;   // re-decode launches of a batch on one table set: eight waves per copy of the tables (refresh; bit 0: round 0, bit 1: later rounds)
     bool fused = true;                         // JD_NODRI_FUSED=0, or a run whose staging overflowed, turns it off for the batch
     bool fused_always = false;                 // JD_NODRI_FUSED=2: whatever the batch's size (tests)
@@ -381,12 +382,25 @@ int refresh(jd_batch* b, hipStream_t s) {
     // -2 % at 16 = 925,000, -7 % at 24, -11 % at 64), 4096 x 4096 from ~30 (+12 % at 16 = 231,000, -6 % at 48): the larger
     // the images the more stream it takes (their per-image steps -- lists, index -- are serial), hence the three-step rule.
     bool fz_now = b->fused;
+    b->f_small_class = false;
     if (fz_now && !b->fused_always) {
-        uint64_t subs = 0, nfz = 0;
+        uint64_t subs = 0, nfz = 0, most = 0;
+        bool one_set = true;                                       // every candidate image on the same packed tables
+        uint32_t set_off = 0, set_len = 0;
         for (int i = 0; i < n; i++)
-            if (b->fz_ok[i]) { subs += ((uint64_t)b->img[i].ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS; nfz++; }
+            if (b->fz_ok[i]) {
+                const uint64_t k = ((uint64_t)b->img[i].ecs_len * 8 + JD_SUBSEQ_BITS - 1) / JD_SUBSEQ_BITS;
+                subs += k; nfz++; most = std::max(most, k);
+                if (!set_len) { set_off = b->img[i].w_off; set_len = b->img[i].w_len; }
+                else if (b->img[i].w_off != set_off || b->img[i].w_len != set_len) one_set = false;
+            }
         const uint64_t avg = nfz ? subs / nfz : 0;
         fz_now = nfz && subs >= (avg <= 4096 ? 250000u : avg <= 20000 ? 450000u : 800000u);
+        // Many SMALL images on one table set (thumbnails; at most 256 sub-sequences each): the path's launches then run
+        // eight waves per copy of the tables (f_share below), and it wins from ~600 images whatever the total -- 320x240:
+        // 500 images +-0, 1000 +25 %, 3000 +65 % against the two-pass path; 640x360: 300 +-0, 600 +10 %, 1200 +13 %.
+        b->f_small_class = nfz >= 600 && one_set && most <= 256 && env_int("JD_DEBUG_FUSED_SHARE", 1) != 0;
+        if (b->f_small_class) fz_now = true;
         // ... and with long sub-sequences once the batch is larger still (8192 bits beat 4096 from ~900,000: 512 x 1080p
         // -13 % against -11 %, 16 x 8192^2 -7 % against -2 %; below, 48 x 4096^2 +1 % against -7 %; at C4 / C5 size -17 % against -11 %)
         b->fsub_bits = subs >= (uint64_t)env_int("JD_DEBUG_FUSED_LONG_FROM", 900000) ? JD_F_SUBSEQ_BITS_MAX : JD_SUBSEQ_BITS;
@@ -445,7 +459,7 @@ int refresh(jd_batch* b, hipStream_t s) {
         if (env_int("JD_DEBUG_FUSED_SHARE", 1) == 0) one_set = false;
         // Only where a workgroup per image would not fit the machine at once (eight one-wave workgroups per CU: 2048): with
         // fewer images the walks are better spread over all CUs (1080p images: 512 - 2 % with sharing, 1024 + 0.5 %, 2048 + 5 %, 5000 + 4 %).
-        const bool many = nfz2 >= (uint64_t)env_int("JD_DEBUG_FUSED_SHARE_FROM", 1200);
+        const bool many = nfz2 >= (uint64_t)env_int("JD_DEBUG_FUSED_SHARE_FROM", b->f_small_class ? 600 : 1200);
         b->f_share = (one_set && many && b->redo0_lanes <= 128u && nsub_max <= 2048u ? 1u : 0u) | (one_set && many && nsub_max <= 8192u ? 2u : 0u);
         // ... and the FIRST decode of a batch of many tiny images (thumbnails: every image a wave or a few): a 512-lane
         // workgroup per image holds 78 KB of LDS for its one busy wave -- two images per CU at a time instead of sixteen

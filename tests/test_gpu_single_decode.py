@@ -333,3 +333,28 @@ def test_first_decode_of_many_small_images_on_one_copy_of_the_tables(biggest, ro
             if rnd == 0:
                 assert np.array_equal(b.download(i), orclib.OracleImage(files[i]).rgb), (rnd, i)
     b.close()
+
+
+def test_many_small_images_on_one_table_set_take_the_path_by_default():
+    """default knobs: 640 small images that share their Huffman tables (no image above 256 sub-sequences) -- far below the
+    rule's 250,000 sub-sequences, but the class for which the single-decode path runs eight waves per copy of the tables
+    and wins from ~600 images (jd_api.cpp, refresh()); 320 of them stay on the two-pass path.  Either way: the oracle's pictures"""
+    kinds = [(96, 64, 2, 2, 3), (64, 48, 1, 1, 3), (160, 120, 2, 1, 3), (8, 8, 2, 2, 3), (120, 90, 1, 2, 3), (320, 240, 2, 2, 3), (17, 9, 1, 1, 3), (250, 33, 2, 2, 3)]
+    ims = [jd.SynthImage(w, h, hs, vs, nc, quality=85, seed=1200 + k, detail=1 + k % 3) for k, (w, h, hs, vs, nc) in enumerate(kinds)]
+    files = [im.encode(0) for im in ims]
+    parsed = [jd.parse(f) for f in files]
+    assert len({(bytes(p[0].huff[0][0].bits), bytes(p[0].huff[1][1].bits)) for p in parsed}) == 1
+    want = [(im.coefficients(), orclib.OracleImage(f).rgb) for im, f in zip(ims, files)]
+    for n in (640, 320):
+        order = [(7 * i + i // 8) % len(kinds) for i in range(n)]
+        b = jd.Batch([parsed[k][0] for k in order], [parsed[k][2] for k in order], keep_coef=True)
+        for rnd in range(2):
+            for i, k in enumerate(order):
+                b.upload(i, files[k][parsed[k][1]:parsed[k][1] + parsed[k][2]])
+            b.run(); b.wait()
+            for i, k in enumerate(order):
+                assert b.status(i) == 0, (n, rnd, i)
+                if i % 5 == 0 or i >= n - 8:
+                    assert np.array_equal(b.coefficients(i), want[k][0]), (n, rnd, i)
+                    assert np.array_equal(b.download(i), want[k][1]), (n, rnd, i)
+        b.close()
